@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json|csv by RUNNING the reference's own pure-Python code.
+
+Runs only in the build container (needs /root/reference); the GPU box and the test
+suite read the committed fixtures, never the reference.  Nothing from the reference
+is copied: the fixtures hold inputs and the outputs the reference computed for them.
+
+Sources executed:
+  * workflow/rules/exp_type_1.smk:115-150  summarize_histogram_type1
+  * workflow/rules/exp_type_1.smk:199-231  body of rule within_group_union_analysis
+  * workflow/rules/exp_type_1.smk:268-297  body of rule across_group_union_analysis
+  * workflow/rules/exp_type_2.smk:171-216  summarize_histogram_type2
+  * src/merge_lists.py                     get_canonical_kmer, process_read_into_kmers
+"""
+import importlib.util
+import json
+import os
+import random
+import sys
+import tempfile
+import textwrap
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _lines(path, lo, hi):
+    with open(path) as fh:
+        src = fh.readlines()
+    return textwrap.dedent("".join(src[lo - 1:hi]))
+
+
+def load_reference():
+    ns1, ns2 = {}, {}
+    exec(_lines(f"{REF}/workflow/rules/exp_type_1.smk", 115, 150), ns1)
+    exec(_lines(f"{REF}/workflow/rules/exp_type_2.smk", 171, 216), ns2)
+    spec = importlib.util.spec_from_file_location("ref_merge_lists", f"{REF}/src/merge_lists.py")
+    ml = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ml)
+    return ns1["summarize_histogram_type1"], ns2["summarize_histogram_type2"], ml
+
+
+def rand_hist(rng, length, n_members, total_scale):
+    """A histogram shaped like a union-of-sets histogram: mass in bins 1..n_members."""
+    h = [0] * length
+    for i in range(min(n_members, length)):
+        h[i] = rng.randrange(0, total_scale) if rng.random() < 0.85 else 0
+    if rng.random() < 0.3:
+        h[0] = rng.randrange(total_scale, 10 * total_scale)
+    if sum(h) == 0:
+        h[0] = 1
+    return h
+
+
+def gen_type1(s1, rng):
+    cases = []
+    for length in (255, 5000, 65535):
+        for n_members in (1, 2, 4, 5, 10, 100):
+            for across in (False, True):
+                for _ in range(3):
+                    k = rng.choice([7, 15, 21, 27, 30, 31, 34, 41, 49, 63])
+                    h = rand_hist(rng, length, n_members if not across else 30,
+                                  rng.choice([10, 1000, 5_000_000]))
+                    try:
+                        m = s1(list(h), n_members, across, k)
+                    except AssertionError:
+                        continue
+                    nz = [(i, v) for i, v in enumerate(h) if v]
+                    cases.append({"len": length, "nonzero": nz, "n_members": n_members,
+                                  "across": across, "k": k, "metrics": m})
+    # edge: everything in bin 1; saturated last bin
+    for length in (255, 65535):
+        h = [0] * length
+        h[0] = 123456
+        cases.append({"len": length, "nonzero": [(0, 123456)], "n_members": 5,
+                      "across": False, "k": 31, "metrics": s1(h, 5, False, 31)})
+        h = [0] * length
+        h[0] = 10
+        h[length - 1] = 7
+        cases.append({"len": length, "nonzero": [(0, 10), (length - 1, 7)], "n_members": 5,
+                      "across": False, "k": 31, "metrics": s1(h, 5, False, 31)})
+    return cases
+
+
+def gen_type2(s2, rng):
+    cases = []
+    for length in (255, 65535):
+        for n in (2, 4, 5, 10, 50):
+            for across in (False, True):
+                for _ in range(3):
+                    k = rng.choice([7, 21, 31, 41])
+                    sub = [0] * length
+                    sub[0] = rng.randrange(1, 5_000_000)
+                    inter = [0] * length
+                    for i in range(1, min(n + 1, length)):
+                        inter[i] = rng.randrange(0, 1_000_000)
+                    try:
+                        m = s2(list(sub), list(inter), n, across, k)
+                    except AssertionError:
+                        continue
+                    cases.append({"len": length, "sub0": sub[0],
+                                  "inter_nonzero": [(i, v) for i, v in enumerate(inter) if v],
+                                  "n": n, "across": across, "k": k, "metrics": m})
+    return cases
+
+
+def gen_canonical(ml, rng):
+    out = {"canonical": [], "windows": []}
+    for k in (1, 2, 7, 15, 21, 27, 30, 31, 32, 33, 41, 63, 64):
+        for _ in range(12):
+            s = "".join(rng.choice("ACGT") for _ in range(k))
+            out["canonical"].append([s, ml.get_canonical_kmer(s)])
+        if k % 2 == 0:   # even-k reverse-complement palindromes
+            half = "".join(rng.choice("ACGT") for _ in range(k // 2))
+            comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+            pal = half + "".join(comp[c] for c in reversed(half))
+            out["canonical"].append([pal, ml.get_canonical_kmer(pal)])
+    for s in ("A" * 31, "T" * 31, "ACGT" * 8, "TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTG"):
+        out["canonical"].append([s, ml.get_canonical_kmer(s)])
+    for L, k in ((0, 3), (2, 3), (3, 3), (10, 4), (40, 31), (70, 63)):
+        s = "".join(rng.choice("ACGT") for _ in range(L))
+        out["windows"].append([s, k, ml.process_read_into_kmers(s, k)])
+    return out
+
+
+def gen_csv(s1, rng):
+    """Run the bodies of the two `run:` blocks on synthetic histogram files."""
+    k_values = ["7", "21", "31"]
+    num_datasets = 3
+    members = {1: 1, 2: 5, 3: 10}
+    smk = f"{REF}/workflow/rules/exp_type_1.smk"
+    within_body = _lines(smk, 199, 231)
+    across_body = _lines(smk, 268, 297)
+    hists = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            within_inputs, across_inputs = [], []
+            for k in k_values:
+                for num in range(1, num_datasets + 1):
+                    p = f"step_4/k_{k}/dataset_{num}/dataset_{num}_k{k}_hist.txt"
+                    os.makedirs(os.path.dirname(p), exist_ok=True)
+                    h = rand_hist(rng, 5000, members[num], 3_000_000)
+                    hists[p] = [(i, v) for i, v in enumerate(h) if v]
+                    with open(p, "w") as fh:
+                        fh.write("".join(f"{i + 1}\t{v}\n" for i, v in enumerate(h)))
+                    within_inputs.append(p)
+            # the expand() order of exp_type_1.smk:195 is k-major? expand iterates the
+            # product with the LAST keyword varying fastest: k_len outer, num inner.
+            for k in k_values:
+                p = f"step_8/k_{k}/all_datasets_k{k}_hist.txt"
+                os.makedirs(os.path.dirname(p), exist_ok=True)
+                h = rand_hist(rng, 5000, num_datasets, 9_000_000)
+                hists[p] = [(i, v) for i, v in enumerate(h) if v]
+                with open(p, "w") as fh:
+                    fh.write("".join(f"{i + 1}\t{v}\n" for i, v in enumerate(h)))
+                across_inputs.append(p)
+            os.makedirs("step_5")
+            os.makedirs("step_9")
+            ns = {"summarize_histogram_type1": s1, "num_datasets": num_datasets,
+                  "get_num_of_dataset_members": lambda d: members[int(d)],
+                  "input": within_inputs, "output": ["step_5/within_datasets_analysis.csv"]}
+            exec(within_body, ns)
+            ns.update(input=across_inputs, output=["step_9/across_datasets_analysis.csv"])
+            exec(across_body, ns)
+            within_csv = open("step_5/within_datasets_analysis.csv").read()
+            across_csv = open("step_9/across_datasets_analysis.csv").read()
+        finally:
+            os.chdir(cwd)
+    return {"k_values": k_values, "num_datasets": num_datasets,
+            "members": {str(a): b for a, b in members.items()}, "hist_len": 5000,
+            "hists": hists, "within_inputs": within_inputs, "across_inputs": across_inputs,
+            "within_csv": within_csv, "across_csv": across_csv}
+
+
+def main():
+    s1, s2, ml = load_reference()
+    rng = random.Random(0x6B686F696365)
+    out = {
+        "summarize_type1.json": gen_type1(s1, rng),
+        "summarize_type2.json": gen_type2(s2, rng),
+        "canonical_kmers.json": gen_canonical(ml, rng),
+        "exp1_csv.json": gen_csv(s1, rng),
+    }
+    for name, obj in out.items():
+        with open(os.path.join(HERE, name), "w") as fh:
+            json.dump(obj, fh, separators=(",", ":"))
+        print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+    print("python", sys.version.split()[0])
+
+
+if __name__ == "__main__":
+    main()
