@@ -1,0 +1,171 @@
+/* khoice_hip.h — C ABI of libkhoice_hip.so, the MI355X (gfx950) k-mer engine.
+ *
+ * The reference (vshiv18/khoice) has no FFI: its boundary to the k-mer engine is
+ * process + argv + files, i.e. Snakemake `shell:` calls to KMC 3.2.1's `kmc` and
+ * `kmc_tools`.  Each entry point below is what a binding for one of those call forms
+ * would bind; the reference call site it replaces is cited as file:line into
+ * /root/reference.  The `kmc` / `kmc_tools` executables shipped in bin/ are thin argv
+ * parsers over exactly these functions.
+ *
+ * Conventions
+ *   - plain C types only; handles are opaque pointers owned by the library
+ *   - every function returns 0 on success or a negative KH_E_* code; the message of the
+ *     last failure on the calling thread is kh_last_error()
+ *   - a kh_ctx owns one HIP stream on one device; calls on one ctx must not overlap,
+ *     different ctxs may be used from different threads / processes concurrently
+ *   - k-mers are 2k-bit integers, first base most significant, A=0 C=1 G=2 T=3;
+ *     host-side key arrays use W = ceil(2k/64) little-endian 64-bit words per key
+ *   - there is NO CPU fallback: without a usable HIP device every call fails
+ */
+#ifndef KHOICE_HIP_H
+#define KHOICE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kh_ctx kh_ctx;
+typedef struct kh_set kh_set;
+
+enum {
+    KH_OK = 0,
+    KH_E_ARG = -1,      /* bad argument */
+    KH_E_HIP = -2,      /* HIP runtime error */
+    KH_E_IO = -3,       /* file error */
+    KH_E_FORMAT = -4,   /* not a khoice_amd database */
+    KH_E_KMISMATCH = -5,/* operands built with different k */
+    KH_E_CAPACITY = -6, /* a bucket could not be fitted after retries */
+    KH_E_INTERNAL = -7,
+    KH_E_NOMEM = -8
+};
+
+/* set operations of `kmc_tools simple` / `complex` */
+enum { KH_UNION = 0, KH_INTERSECT = 1, KH_KMERS_SUBTRACT = 2, KH_COUNTERS_SUBTRACT = 3 };
+/* counter calculation modes, `-oc<mode>` */
+enum { KH_MODE_MIN = 0, KH_MODE_MAX = 1, KH_MODE_SUM = 2, KH_MODE_DIFF = 3,
+       KH_MODE_LEFT = 4, KH_MODE_RIGHT = 5 };
+
+#define KH_NO_MAX 0xffffffffu          /* cx: no upper cut-off */
+#define KH_KMC_DEFAULT_CS 255u         /* kmc / kmc_tools default counter saturation */
+
+/* ---------------------------------------------------------------- context */
+int kh_ctx_create(int device, kh_ctx **out);
+void kh_ctx_destroy(kh_ctx *ctx);
+const char *kh_last_error(void);
+int kh_device_count(void);
+/* JSON: device, op counts, bytes/keys processed, per-kernel-class time when profiling */
+int kh_stats(kh_ctx *ctx, char *buf, size_t buflen);
+/* record HIP events around every kernel class (adds a sync when stats are read) */
+int kh_profile_enable(kh_ctx *ctx, int on);
+int kh_stats_reset(kh_ctx *ctx);
+int kh_sync(kh_ctx *ctx);
+/* release cached device allocations */
+int kh_trim(kh_ctx *ctx);
+
+/* ---------------------------------------------------------------- K1: build
+ * `kmc -fm -m64 -k{k} -ci1 IN.fna.gz OUT tmp/`   workflow/rules/exp_type_1.smk:163
+ * (also exp_type_2.smk:297,306; exp_type_3.smk:183,192; exp_type_4.smk:143,152;
+ * exp_type_6.smk:171,181).  Canonical counting; symbols other than ACGTacgt break a run;
+ * keep ci <= count <= cx; counters saturate at cs.
+ *
+ * kh_build_batch: nseq sequences in ONE launch sequence.  seqs[i] points at len[i] bytes
+ * of cleaned sequence text (records separated by any non-ACGT byte, e.g. '\n'); host
+ * pointers when on_device == 0, device pointers (any alignment) when on_device != 0.
+ * with_counts == 0 builds plain sets (every counter 1): the fused form of
+ * `kmc ...` followed by `kmc_tools transform ... set_counts 1` (exp_type_1.smk:163+173).
+ */
+int kh_build_batch(kh_ctx *ctx, int nseq, const uint8_t *const *seqs, const uint64_t *lens,
+                   int on_device, int k, uint32_t ci, uint32_t cx, uint32_t cs, int with_counts,
+                   kh_set **out_sets);
+/* one (gz) multi-FASTA file -> one set; host ingest (inflate + record parsing) included */
+int kh_build_fasta(kh_ctx *ctx, const char *path, int k, uint32_t ci, uint32_t cx, uint32_t cs,
+                   kh_set **out);
+/* ingest only: cleaned sequence text of a (gz) multi-FASTA; caller frees with kh_free_host */
+int kh_read_fasta(const char *path, uint8_t **seq, uint64_t *len);
+void kh_free_host(void *p);
+
+/* ---------------------------------------------------------------- K2: set_counts
+ * `kmc_tools transform IN set_counts {v} OUT`     exp_type_1.smk:173,241
+ * O(1): the result shares IN's key storage and carries a uniform counter. */
+int kh_set_counts(kh_ctx *ctx, const kh_set *in, uint32_t value, kh_set **out);
+
+/* ---------------------------------------------------------------- K3: complex union
+ * `kmc_tools complex OPS.txt` with  out = (set1 + set2 + ... ), OUTPUT_PARAMS -cs{cs}
+ * ops file written at exp_type_1.smk:52-61,75-84; call sites :182,:250.
+ * Counters add and saturate at cs.  hist (optional, may be NULL) receives the counter
+ * histogram of the result fused into the same pass (K4): hist[c] for c in [0,hist_len),
+ * counters >= hist_len fall into the last bin. */
+int kh_union_sum(kh_ctx *ctx, const kh_set *const *sets, int nsets, uint32_t cs, kh_set **out,
+                 uint64_t *hist, uint32_t hist_len);
+
+/* ---------------------------------------------------------------- K5/K6: simple
+ * `kmc_tools simple A B intersect OUT -ocsum`     exp_type_2.smk:363-365,479-481
+ * `kmc_tools simple A B kmers_subtract OUT`       exp_type_2.smk:377-379,493-495
+ * op: KH_UNION | KH_INTERSECT | KH_KMERS_SUBTRACT | KH_COUNTERS_SUBTRACT */
+int kh_simple(kh_ctx *ctx, const kh_set *a, const kh_set *b, int op, int mode, uint32_t cs,
+              kh_set **out);
+
+/* ---------------------------------------------------------------- K4: histogram
+ * `kmc_tools transform IN histogram OUT.txt`      exp_type_1.smk:191,259
+ * hist[c], c in [0, hist_len); counters >= hist_len are added to the last bin. */
+int kh_histogram(kh_ctx *ctx, const kh_set *set, uint64_t *hist, uint32_t hist_len);
+/* text form consumed at exp_type_1.smk:210-212: lines "c<TAB>n", c = 1..cmax */
+int kh_histogram_file(kh_ctx *ctx, const kh_set *set, uint32_t cmax, const char *path);
+
+/* ---------------------------------------------------------------- K7: sorted dump
+ * `kmc_tools transform IN dump -s OUT.txt`        exp_type_4.smk:255-257,268-270
+ * lines "KMER<TAB>count", sorted A<C<G<T (consumer src/merge_lists.py:19-22). */
+int kh_dump_sorted(kh_ctx *ctx, const kh_set *set, const char *path);
+
+/* ---------------------------------------------------------------- set handles */
+void kh_set_free(kh_set *set);
+int kh_set_info(const kh_set *set, uint64_t *n, int *k, int *words_per_key, int *has_counts,
+                uint32_t *uniform_count);
+/* copy to host in storage order (NOT sorted by key): keys un-mixed, n*W words; counts n */
+int kh_set_download(kh_ctx *ctx, const kh_set *set, uint64_t *keys, uint32_t *counts);
+/* build a set from host arrays of DISTINCT keys in any order (counts may be NULL => 1) */
+int kh_set_upload(kh_ctx *ctx, int k, uint64_t n, const uint64_t *keys, const uint32_t *counts,
+                  kh_set **out);
+/* raw device views for zero-copy exchange (multi-GPU): mixed keys sorted ascending,
+ * counts NULL when uniform.  Valid until the set is freed. */
+int kh_set_device_ptrs(const kh_set *set, const void **keys_mixed, const uint32_t **counts);
+/* wrap device arrays of already mixed, sorted, distinct keys (copied into the library) */
+int kh_set_from_device(kh_ctx *ctx, int k, uint64_t n, const void *keys_mixed,
+                       const uint32_t *counts, kh_set **out);
+/* index of the first key of every one of `nparts` equal-width slots of the mixed key
+ * space: bounds[nparts+1] (host).  Used to slice a set for the all-to-all exchange. */
+int kh_set_partition_bounds(kh_ctx *ctx, const kh_set *set, uint32_t nparts, uint64_t *bounds);
+
+/* ---------------------------------------------------------------- database files
+ * `<prefix>.kmc_pre` + `<prefix>.kmc_suf` (names required by the Snakemake rules,
+ * exp_type_1.smk:160-161); khoice_amd container format, written atomically. */
+int kh_save(kh_ctx *ctx, const kh_set *set, const char *prefix);
+int kh_load(kh_ctx *ctx, const char *prefix, kh_set **out);
+
+/* ---------------------------------------------------------------- fused experiment type 1
+ * The whole device side of exp_type_1.smk:156-259 for one k on resident sequences:
+ * per genome build+set (steps 1-2), per group union-sum + histogram (steps 3-4),
+ * group sets (step 6), across-group union-sum + histogram (steps 7-8).
+ *   group_of[i]    group index (0-based) of sequence i; ngroups groups
+ *   within_hist    [ngroups * hist_len]  step_4 histograms
+ *   across_hist    [hist_len]            step_8 histogram
+ *   distinct_per_seq [nseq]              distinct canonical k-mers of each genome
+ *   group_sets     optional [ngroups]: the step_3 group unions (caller frees)
+ *   across_set     optional: the step_7 union (caller frees)
+ */
+int kh_exp1_run(kh_ctx *ctx, int nseq, const uint8_t *const *seqs, const uint64_t *lens,
+                int on_device, const int *group_of, int ngroups, int k, uint32_t cs,
+                uint64_t *within_hist, uint64_t *across_hist, uint32_t hist_len,
+                uint64_t *distinct_per_seq, kh_set **group_sets, kh_set **across_set);
+
+/* host-side helpers exposed for tests (no device work) */
+void kh_mix_host(int k, const uint64_t *key_words, uint64_t *out_words);
+void kh_unmix_host(int k, const uint64_t *key_words, uint64_t *out_words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KHOICE_HIP_H */

@@ -1,0 +1,152 @@
+// khoice_amd — shared host/device definitions for the k-mer engine.
+//
+// Key model
+// ---------
+// A k-mer of length k (1..64) is the integer whose base i (0 = leftmost) sits in bits
+// [2(k-1-i)+1 : 2(k-1-i)], A=0 C=1 G=2 T=3, so integer order == lexicographic order
+// (the order `kmc_tools transform dump -s` prints, src/merge_lists.py:19-22 consumer).
+// W = ceil(2k/64) 64-bit words per key, little-endian word order (w[0] = low word).
+//
+// Every set the engine keeps in HBM stores MIXED keys: key' = mix_k(key), a bijection
+// on 2k-bit integers, and is sorted by key'.  Mixing makes the top bits uniform whatever
+// the genome's base composition, so fixed-width bucket / range splits are balanced and
+// a bucket always fits LDS; because the map is a bijection the sorted-by-key' order is a
+// consistent total order across sets, which is all union / intersect / subtract need.
+// Keys are un-mixed on download and re-sorted only for the sorted text dump (K7).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define KH_HD __host__ __device__ __forceinline__
+#else
+#define KH_HD inline
+#endif
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+template <int W> struct KmerKey;
+template <> struct KmerKey<1> { u64 lo; };
+template <> struct alignas(16) KmerKey<2> { u64 lo, hi; };
+
+KH_HD bool key_lt(const KmerKey<1>& a, const KmerKey<1>& b) { return a.lo < b.lo; }
+KH_HD bool key_eq(const KmerKey<1>& a, const KmerKey<1>& b) { return a.lo == b.lo; }
+KH_HD bool key_lt(const KmerKey<2>& a, const KmerKey<2>& b) {
+    return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo);
+}
+KH_HD bool key_eq(const KmerKey<2>& a, const KmerKey<2>& b) { return a.hi == b.hi && a.lo == b.lo; }
+KH_HD void key_set_max(KmerKey<1>& a) { a.lo = ~0ull; }
+KH_HD void key_set_max(KmerKey<2>& a) { a.lo = ~0ull; a.hi = ~0ull; }
+
+KH_HD u64 kh_mask(int nbits) { return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull); }
+
+// ---------------------------------------------------------------- bijective mixing
+constexpr u64 KH_C1 = 0xff51afd7ed558ccdull;   // odd multipliers (murmur3 / splitmix family)
+constexpr u64 KH_C2 = 0xc4ceb9fe1a85ec53ull;
+constexpr u64 KH_C3 = 0x9e3779b97f4a7c15ull;
+constexpr u64 KH_C4 = 0xbf58476d1ce4e5b9ull;
+constexpr u64 KH_C5 = 0x94d049bb133111ebull;
+
+constexpr u64 kh_modinv(u64 c) {   // inverse of odd c modulo 2^64 (Newton)
+    u64 x = c;
+    for (int i = 0; i < 6; ++i) x *= 2 - c * x;
+    return x;
+}
+constexpr u64 KH_C1_INV = kh_modinv(KH_C1);
+constexpr u64 KH_C2_INV = kh_modinv(KH_C2);
+static_assert(KH_C1 * KH_C1_INV == 1ull && KH_C2 * KH_C2_INV == 1ull, "modinv");
+
+// bijection on [0, 2^n), 2 <= n <= 64.  s >= n/2 so one xor-shift step is its own inverse.
+KH_HD u64 kh_mix64(u64 x, int n) {
+    const u64 M = kh_mask(n);
+    const int s = (n + 1) >> 1;
+    x ^= x >> s;
+    x = (x * KH_C1) & M;
+    x ^= x >> s;
+    x = (x * KH_C2) & M;
+    x ^= x >> s;
+    return x;
+}
+KH_HD u64 kh_unmix64(u64 x, int n) {
+    const u64 M = kh_mask(n);
+    const int s = (n + 1) >> 1;
+    x ^= x >> s;
+    x = (x * KH_C2_INV) & M;
+    x ^= x >> s;
+    x = (x * KH_C1_INV) & M;
+    x ^= x >> s;
+    return x;
+}
+// keyed 64-bit scrambler (need not be invertible: used as a Feistel round function)
+KH_HD u64 kh_round(u64 v, u64 c) {
+    v ^= v >> 32;
+    v *= c;
+    v ^= v >> 29;
+    v *= KH_C5;
+    v ^= v >> 32;
+    return v;
+}
+
+KH_HD KmerKey<1> kh_mix(KmerKey<1> a, int k) { a.lo = kh_mix64(a.lo, 2 * k); return a; }
+KH_HD KmerKey<1> kh_unmix(KmerKey<1> a, int k) { a.lo = kh_unmix64(a.lo, 2 * k); return a; }
+// 64 < 2k <= 128: hi holds nh = 2k-64 bits.  Unbalanced Feistel around two 64-bit bijections.
+KH_HD KmerKey<2> kh_mix(KmerKey<2> a, int k) {
+    const u64 MH = kh_mask(2 * k - 64);
+    a.lo = kh_mix64(a.lo, 64);
+    a.hi ^= kh_round(a.lo, KH_C3) & MH;
+    a.lo ^= kh_round(a.hi, KH_C4);
+    a.lo = kh_mix64(a.lo, 64);
+    a.hi ^= kh_round(a.lo, KH_C1) & MH;
+    return a;
+}
+KH_HD KmerKey<2> kh_unmix(KmerKey<2> a, int k) {
+    const u64 MH = kh_mask(2 * k - 64);
+    a.hi ^= kh_round(a.lo, KH_C1) & MH;
+    a.lo = kh_unmix64(a.lo, 64);
+    a.lo ^= kh_round(a.hi, KH_C4);
+    a.hi ^= kh_round(a.lo, KH_C3) & MH;
+    a.lo = kh_unmix64(a.lo, 64);
+    return a;
+}
+
+// top 32 bits of the 2k-bit mixed key (left-aligned when 2k < 32): monotone in key'.
+KH_HD u32 kh_top32(const KmerKey<1>& a, int k) {
+    const int n = 2 * k;
+    return n >= 32 ? (u32)(a.lo >> (n - 32)) : (u32)(a.lo << (32 - n));
+}
+KH_HD u32 kh_top32(const KmerKey<2>& a, int k) {
+    const int nh = 2 * k - 64;   // 1..64
+    if (nh >= 32) return (u32)(a.hi >> (nh - 32));
+    return (u32)((a.hi << (32 - nh)) | (a.lo >> (32 + nh)));
+}
+// slot of a mixed key among `nslots` equal-width, order-preserving slots
+template <int W> KH_HD u32 kh_slot(const KmerKey<W>& a, int k, u32 nslots) {
+    return (u32)(((u64)kh_top32(a, k) * (u64)nslots) >> 32);
+}
+
+// ---------------------------------------------------------------- engine constants
+constexpr int KH_SUBTILE = 8192;            // k-mer start positions per sub-tile (256 thr x 32)
+constexpr int KH_SUBTILES_PER_TILE = 8;     // one workgroup walks 8 sub-tiles = 65536 positions
+constexpr int KH_TILE = KH_SUBTILE * KH_SUBTILES_PER_TILE;
+constexpr int KH_MAX_BUCKETS_PER_SEG = 16384;   // LDS cursor array limit (64 KiB)
+constexpr int KH_BUCKET_MEAN_W1 = 3400;     // target keys per bucket (typical P = 4096)
+constexpr int KH_BUCKET_MEAN_W2 = 1700;
+constexpr int KH_SORT_CAP_W1 = 7168;        // LDS sort capacity in keys (56 KiB of keys, 2 WG/CU)
+constexpr int KH_SORT_CAP_W2 = 3584;
+constexpr int KH_SORT_CAP_PAY_W1 = 4736;    // capacity with a 32-bit payload per key
+constexpr int KH_SORT_CAP_PAY_W2 = 2816;
+constexpr int KH_SORT_THREADS = 512;
+constexpr int KH_MAX_INPUT_SETS = 64;       // fan-in of one set-operation launch
+constexpr int KH_LHIST_BINS = 512;          // LDS histogram bins fused into set-ops
+
+enum KhSetOp : int {
+    KH_OP_UNION = 0,             // n-ary or binary union, counters combined by `mode`
+    KH_OP_INTERSECT = 1,
+    KH_OP_KMERS_SUBTRACT = 2,
+    KH_OP_COUNTERS_SUBTRACT = 3,
+};
+enum KhCounterMode : int {       // kmc_tools -oc<mode>
+    KH_OC_MIN = 0, KH_OC_MAX = 1, KH_OC_SUM = 2, KH_OC_DIFF = 3, KH_OC_LEFT = 4, KH_OC_RIGHT = 5,
+};

@@ -1,0 +1,769 @@
+// khoice_amd — host side of libkhoice_hip.so: context, device memory pool, set handles,
+// orchestration of the gfx950 kernels and the C ABI declared in include/khoice_hip.h.
+// There is deliberately no CPU implementation of any operation in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/khoice_hip.h"
+#include "kh_engine.h"
+#include "kh_launch.h"
+
+// ------------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+
+int kh_fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+extern "C" const char* kh_last_error(void) { return g_last_error.c_str(); }
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return kh_fail(KH_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                           __FILE__, __LINE__);                                           \
+    } while (0)
+#define KHCHK(expr)                  \
+    do {                             \
+        int r__ = (expr);            \
+        if (r__ != KH_OK) return r__; \
+    } while (0)
+
+// ------------------------------------------------------------------------------ pool
+// Stream-ordered caching allocator: every user of a ctx runs on its single stream, so a
+// block released by one operation can be handed to the next without synchronising.
+void* Pool::alloc(size_t bytes, size_t* got) {
+    if (bytes == 0) bytes = 256;
+    size_t want = (bytes + 255) & ~(size_t)255;
+    if (want > (1u << 20)) want = (want + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    auto it = free_.lower_bound(want);
+    if (it != free_.end() && it->first <= want + want / 4 + (1u << 20)) {
+        void* p = it->second;
+        *got = it->first;
+        cached_bytes -= it->first;
+        free_.erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        trim();
+        e = hipMalloc(&p, want);
+        if (e != hipSuccess) return nullptr;
+    }
+    total_bytes += want;
+    *got = want;
+    return p;
+}
+void Pool::release(void* p, size_t bytes) {
+    free_.emplace(bytes, p);
+    cached_bytes += bytes;
+}
+void Pool::trim() {
+    for (auto& kv : free_) {
+        (void)hipFree(kv.second);
+        total_bytes -= kv.first;
+    }
+    free_.clear();
+    cached_bytes = 0;
+}
+
+DevBuf* kh_ctx::buf_alloc(size_t bytes) {
+    size_t got = 0;
+    void* p = pool.alloc(bytes, &got);
+    if (!p) return nullptr;
+    DevBuf* b = new DevBuf;
+    b->p = p;
+    b->bytes = got;
+    b->refs = 1;
+    b->ctx = this;
+    return b;
+}
+void buf_ref(DevBuf* b) { if (b) b->refs.fetch_add(1); }
+void buf_unref(DevBuf* b) {
+    if (!b) return;
+    if (b->refs.fetch_sub(1) == 1) {
+        b->ctx->pool.release(b->p, b->bytes);
+        delete b;
+    }
+}
+// scoped temporary
+struct Tmp {
+    DevBuf* b = nullptr;
+    ~Tmp() { buf_unref(b); }
+    template <class T> T* as() const { return reinterpret_cast<T*>(b->p); }
+};
+#define TMP_ALLOC(tmp, ctx, bytes)                                                        \
+    do {                                                                                  \
+        (tmp).b = (ctx)->buf_alloc(bytes);                                                \
+        if (!(tmp).b) return kh_fail(KH_E_NOMEM, "device allocation of %zu bytes failed", \
+                                     (size_t)(bytes));                                    \
+    } while (0)
+
+// ------------------------------------------------------------------------------ profiling
+void kh_ctx::prof_begin(int cls) {
+    if (!profile) return;
+    ProfEvt ev;
+    ev.cls = cls;
+    (void)hipEventCreate(&ev.a);
+    (void)hipEventCreate(&ev.b);
+    (void)hipEventRecord(ev.a, st);
+    evts.push_back(ev);
+}
+void kh_ctx::prof_end() {
+    if (!profile || evts.empty()) return;
+    (void)hipEventRecord(evts.back().b, st);
+}
+void kh_ctx::prof_collect() {
+    if (evts.empty()) return;
+    (void)hipStreamSynchronize(st);
+    for (auto& ev : evts) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+            cls_ms[ev.cls] += ms;
+            cls_n[ev.cls] += 1;
+        }
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    evts.clear();
+}
+static const char* kClsNames[KC_COUNT] = {"extract_hist", "bucket_plan", "extract_scatter",
+                                          "bucket_sort_rle", "range_bounds", "setop", "histogram",
+                                          "remix", "copy_in"};
+
+// ------------------------------------------------------------------------------ ctx API
+extern "C" int kh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int kh_ctx_create(int device, kh_ctx** out) {
+    if (!out) return kh_fail(KH_E_ARG, "kh_ctx_create: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return kh_fail(KH_E_HIP, "no HIP device available (%s); khoice_amd has no CPU fallback",
+                       e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return kh_fail(KH_E_ARG, "device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    kh_ctx* c = new kh_ctx;
+    c->dev = device;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->arch = prop.gcnArchName;
+    c->cus = prop.multiProcessorCount;
+    if (c->arch.find("gfx950") == std::string::npos && !getenv("KHOICE_ALLOW_ANY_ARCH")) {
+        std::string a = c->arch;
+        delete c;
+        return kh_fail(KH_E_HIP, "device %d is %s; this library carries gfx950 code only", device,
+                       a.c_str());
+    }
+    HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    *out = c;
+    return KH_OK;
+}
+extern "C" void kh_ctx_destroy(kh_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    (void)hipStreamSynchronize(c->st);
+    c->prof_collect();
+    c->pool.trim();
+    (void)hipStreamDestroy(c->st);
+    delete c;
+}
+extern "C" int kh_sync(kh_ctx* c) {
+    if (!c) return kh_fail(KH_E_ARG, "ctx is NULL");
+    HIPCHK(hipStreamSynchronize(c->st));
+    return KH_OK;
+}
+extern "C" int kh_trim(kh_ctx* c) {
+    if (!c) return kh_fail(KH_E_ARG, "ctx is NULL");
+    HIPCHK(hipStreamSynchronize(c->st));
+    c->pool.trim();
+    return KH_OK;
+}
+extern "C" int kh_profile_enable(kh_ctx* c, int on) {
+    if (!c) return kh_fail(KH_E_ARG, "ctx is NULL");
+    c->prof_collect();
+    c->profile = on != 0;
+    return KH_OK;
+}
+extern "C" int kh_stats_reset(kh_ctx* c) {
+    if (!c) return kh_fail(KH_E_ARG, "ctx is NULL");
+    c->prof_collect();
+    for (int i = 0; i < KC_COUNT; ++i) { c->cls_ms[i] = 0; c->cls_n[i] = 0; }
+    c->stat = Stats();
+    return KH_OK;
+}
+extern "C" int kh_stats(kh_ctx* c, char* buf, size_t buflen) {
+    if (!c || !buf) return kh_fail(KH_E_ARG, "kh_stats: NULL argument");
+    c->prof_collect();
+    std::string s = "{";
+    char t[256];
+    snprintf(t, sizeof t, "\"device\":%d,\"arch\":\"%s\",\"cus\":%d,", c->dev, c->arch.c_str(), c->cus);
+    s += t;
+    snprintf(t, sizeof t,
+             "\"builds\":%llu,\"bases\":%llu,\"kmers\":%llu,\"distinct\":%llu,\"setops\":%llu,"
+             "\"setop_in\":%llu,\"setop_out\":%llu,\"retries\":%llu,\"pool_bytes\":%zu,",
+             (unsigned long long)c->stat.builds, (unsigned long long)c->stat.bases,
+             (unsigned long long)c->stat.kmers, (unsigned long long)c->stat.distinct,
+             (unsigned long long)c->stat.setops, (unsigned long long)c->stat.setop_in,
+             (unsigned long long)c->stat.setop_out, (unsigned long long)c->stat.retries,
+             c->pool.total_bytes);
+    s += t;
+    s += "\"kernels\":{";
+    for (int i = 0; i < KC_COUNT; ++i) {
+        snprintf(t, sizeof t, "%s\"%s\":{\"ms\":%.6f,\"launches\":%llu}", i ? "," : "", kClsNames[i],
+                 c->cls_ms[i], (unsigned long long)c->cls_n[i]);
+        s += t;
+    }
+    s += "}}";
+    if (s.size() + 1 > buflen) return kh_fail(KH_E_ARG, "kh_stats: buffer too small (%zu needed)", s.size() + 1);
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return KH_OK;
+}
+
+// ------------------------------------------------------------------------------ sets
+extern "C" void kh_set_free(kh_set* s) {
+    if (!s) return;
+    buf_unref(s->kb);
+    buf_unref(s->cb);
+    delete s;
+}
+extern "C" int kh_set_info(const kh_set* s, uint64_t* n, int* k, int* w, int* has_counts,
+                           uint32_t* uniform) {
+    if (!s) return kh_fail(KH_E_ARG, "set is NULL");
+    if (n) *n = s->n;
+    if (k) *k = s->k;
+    if (w) *w = s->W;
+    if (has_counts) *has_counts = s->cb != nullptr;
+    if (uniform) *uniform = s->uniform;
+    return KH_OK;
+}
+static kh_set* make_set(int k, u64 n, DevBuf* kb, size_t koff, DevBuf* cb, size_t coff, u32 uniform) {
+    kh_set* s = new kh_set;
+    s->k = k;
+    s->W = k <= 32 ? 1 : 2;
+    s->n = n;
+    s->kb = kb;
+    s->koff = koff;
+    s->cb = cb;
+    s->coff = coff;
+    s->uniform = uniform;
+    return s;
+}
+static int check_k(int k) {
+    if (k < 1 || k > 64) return kh_fail(KH_E_ARG, "k=%d outside the supported range 1..64", k);
+    return KH_OK;
+}
+
+extern "C" int kh_set_device_ptrs(const kh_set* s, const void** keys, const uint32_t** counts) {
+    if (!s) return kh_fail(KH_E_ARG, "set is NULL");
+    if (keys) *keys = s->n ? s->keys_ptr() : nullptr;
+    if (counts) *counts = s->counts_ptr();
+    return KH_OK;
+}
+
+extern "C" int kh_set_counts(kh_ctx* c, const kh_set* in, uint32_t value, kh_set** out) {
+    if (!c || !in || !out) return kh_fail(KH_E_ARG, "kh_set_counts: NULL argument");
+    if (value == 0) return kh_fail(KH_E_ARG, "set_counts 0 would empty the database");
+    buf_ref(in->kb);
+    *out = make_set(in->k, in->n, in->kb, in->koff, nullptr, 0, value);
+    return KH_OK;
+}
+
+// ------------------------------------------------------------------------------ K1 build
+static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
+                      int on_device, int k, u32 ci, u32 cx, u32 cs, int with_counts, u32 mean,
+                      kh_set** out_sets, bool* capacity_hit) {
+    const int W = k <= 32 ? 1 : 2;
+    const size_t kb = 8 * (size_t)W;
+    hipStream_t st = c->st;
+    *capacity_hit = false;
+
+    // ---- segment layout
+    std::vector<KhSeg> segs(nseq);
+    std::vector<KhTile> tiles;
+    u64 seq_bytes = 0, total_pos = 0, thist_n = 0;
+    u32 nb_total = 0, max_nb = 1;
+    for (int i = 0; i < nseq; ++i) {
+        KhSeg& s = segs[i];
+        s.seq_off = seq_bytes;
+        s.len = lens[i];
+        s.npos = lens[i] >= (u64)k ? lens[i] - k + 1 : 0;
+        const u64 want_b = std::max<u64>(1, (s.npos + mean - 1) / mean);
+        if (want_b > KH_MAX_BUCKETS_PER_SEG)
+            return kh_fail(KH_E_ARG,
+                           "sequence %d has %llu k-mer positions; at most %llu per sequence are "
+                           "supported by this build",
+                           i, (unsigned long long)s.npos,
+                           (unsigned long long)KH_MAX_BUCKETS_PER_SEG * mean);
+        s.nbuckets = (u32)want_b;
+        s.bucket_base = nb_total;
+        s.ntiles = (u32)((s.npos + KH_TILE - 1) / KH_TILE);
+        s.tile_base = (u32)tiles.size();
+        s.thist_base = thist_n;
+        for (u32 t = 0; t < s.ntiles; ++t) tiles.push_back(KhTile{(u32)i, t});
+        thist_n += (u64)s.ntiles * s.nbuckets;
+        nb_total += s.nbuckets;
+        max_nb = std::max(max_nb, s.nbuckets);
+        total_pos += s.npos;
+        seq_bytes += (lens[i] + 15) & ~15ull;
+        c->stat.bases += lens[i];
+    }
+    seq_bytes += 256;   // tail padding: 16-byte loads may run past the last base
+    const u32 ntiles = (u32)tiles.size();
+    const u32 nb_alloc = (max_nb + 3) & ~3u;
+
+    // ---- device buffers
+    Tmp d_seq, d_segs, d_tiles, d_thist, d_tot, d_bstart, d_part, d_lb;
+    TMP_ALLOC(d_seq, c, seq_bytes);
+    TMP_ALLOC(d_segs, c, sizeof(KhSeg) * nseq);
+    TMP_ALLOC(d_tiles, c, sizeof(KhTile) * std::max<u32>(1, ntiles));
+    TMP_ALLOC(d_thist, c, 4 * std::max<u64>(1, thist_n));
+    TMP_ALLOC(d_tot, c, 8 * (u64)nb_total);
+    TMP_ALLOC(d_bstart, c, 8 * ((u64)nb_total + 1));
+    TMP_ALLOC(d_part, c, kb * std::max<u64>(1, total_pos));
+    TMP_ALLOC(d_lb, c, 8 * (u64)nb_total + 64);
+    DevBuf* okeys = c->buf_alloc(kb * std::max<u64>(1, total_pos));
+    if (!okeys) return kh_fail(KH_E_NOMEM, "device allocation failed (output keys)");
+    DevBuf* ocnt = nullptr;
+    if (with_counts) {
+        ocnt = c->buf_alloc(4 * std::max<u64>(1, total_pos));
+        if (!ocnt) { buf_unref(okeys); return kh_fail(KH_E_NOMEM, "device allocation failed (counts)"); }
+    }
+    struct Guard { DevBuf *a, *b; ~Guard() { buf_unref(a); buf_unref(b); } } guard{okeys, ocnt};
+
+    c->prof_begin(KC_COPY_IN);
+    for (int i = 0; i < nseq; ++i) {
+        if (!lens[i]) continue;
+        HIPCHK(hipMemcpyAsync(d_seq.as<u8>() + segs[i].seq_off, seqs[i], lens[i],
+                              on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemcpyAsync(d_segs.b->p, segs.data(), sizeof(KhSeg) * nseq, hipMemcpyHostToDevice, st));
+    if (ntiles)
+        HIPCHK(hipMemcpyAsync(d_tiles.b->p, tiles.data(), sizeof(KhTile) * ntiles, hipMemcpyHostToDevice, st));
+    c->prof_end();
+
+    // ---- pass A, bucket plan, pass B
+    c->prof_begin(KC_EXTRACT_HIST);
+    kh_launch_extract(W, false, d_seq.as<u8>(), d_segs.as<KhSeg>(), d_tiles.as<KhTile>(), ntiles,
+                      nb_alloc, k, d_thist.as<u32>(), nullptr, nullptr, st);
+    c->prof_end();
+    c->prof_begin(KC_BUCKET_PLAN);
+    kh_launch_col_totals(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_tot.as<u64>(), st);
+    kh_launch_exscan(d_tot.as<u64>(), d_bstart.as<u64>(), nb_total, st);
+    kh_launch_col_offsets(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(), st);
+    c->prof_end();
+    c->prof_begin(KC_EXTRACT_SCATTER);
+    kh_launch_extract(W, true, d_seq.as<u8>(), d_segs.as<KhSeg>(), d_tiles.as<KhTile>(), ntiles,
+                      nb_alloc, k, d_thist.as<u32>(), d_bstart.as<u64>(), d_part.b->p, st);
+    c->prof_end();
+
+    // ---- pass C
+    KhLookback lb;
+    lb.desc = d_lb.as<u64>();
+    lb.ticket = reinterpret_cast<u32*>(d_lb.as<u64>() + nb_total);
+    lb.err = lb.ticket + 1;
+    HIPCHK(hipMemsetAsync(d_lb.b->p, 0, 8 * (u64)nb_total + 64, st));
+    c->prof_begin(KC_BUCKET_SORT);
+    kh_launch_bucket_sort(W, d_part.b->p, d_bstart.as<u64>(), nb_total, k, okeys->p,
+                          ocnt ? reinterpret_cast<u32*>(ocnt->p) : nullptr, lb, ci, cx, cs, st);
+    c->prof_end();
+    HIPCHK(hipGetLastError());
+
+    // ---- read back set boundaries
+    std::vector<u64> desc((size_t)nb_total + 8);
+    HIPCHK(hipMemcpyAsync(desc.data(), d_lb.b->p, 8 * (u64)nb_total + 64, hipMemcpyDeviceToHost, st));
+    u64 nvalid = 0;
+    HIPCHK(hipMemcpyAsync(&nvalid, d_bstart.as<u64>() + nb_total, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const u32 err = reinterpret_cast<const u32*>(&desc[nb_total])[1];
+    if (err & KH_ERR_SPIN_TIMEOUT) return kh_fail(KH_E_INTERNAL, "look-back spin timed out in bucket sort");
+    if (err & KH_ERR_CAPACITY) { *capacity_hit = true; return KH_OK; }
+    c->stat.kmers += nvalid;
+
+    u64 prev = 0;
+    for (int i = 0; i < nseq; ++i) {
+        const u64 incl = desc[segs[i].bucket_base + segs[i].nbuckets - 1] & ((1ull << 62) - 1);
+        const u64 n = incl - prev;
+        buf_ref(okeys);
+        if (ocnt) buf_ref(ocnt);
+        out_sets[i] = make_set(k, n, okeys, prev * kb, ocnt, prev * 4, 1);
+        c->stat.distinct += n;
+        prev = incl;
+    }
+    c->stat.builds += nseq;
+    return KH_OK;
+}
+
+extern "C" int kh_build_batch(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
+                              int on_device, int k, uint32_t ci, uint32_t cx, uint32_t cs,
+                              int with_counts, kh_set** out_sets) {
+    if (!c || !seqs || !lens || !out_sets || nseq <= 0) return kh_fail(KH_E_ARG, "kh_build_batch: bad argument");
+    KHCHK(check_k(k));
+    if (ci < 1) ci = 1;
+    if (cs < 1) return kh_fail(KH_E_ARG, "cs must be >= 1");
+    HIPCHK(hipSetDevice(c->dev));
+    u32 mean = k <= 32 ? KH_BUCKET_MEAN_W1 : KH_BUCKET_MEAN_W2;
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        bool cap = false;
+        for (int i = 0; i < nseq; ++i) out_sets[i] = nullptr;
+        int r = build_once(c, nseq, seqs, lens, on_device, k, ci, cx, cs, with_counts, mean, out_sets, &cap);
+        if (r != KH_OK) return r;
+        if (!cap) return KH_OK;
+        c->stat.retries++;
+        mean = std::max<u32>(64, mean / 4);
+    }
+    return kh_fail(KH_E_CAPACITY, "a bucket still holds more distinct k-mers than fit in LDS after 5 re-plans");
+}
+
+// ------------------------------------------------------------------------------ set ops
+static int run_setop(kh_ctx* c, const std::vector<const kh_set*>& in, int op, int mode, u32 cs,
+                     kh_set** out, uint64_t* hist, u32 hist_len) {
+    const int nsets = (int)in.size();
+    const int k = in[0]->k, W = in[0]->W;
+    const size_t kb = 8 * (size_t)W;
+    hipStream_t st = c->st;
+    for (auto* s : in)
+        if (s->k != k) return kh_fail(KH_E_KMISMATCH, "operands built with different k (%d vs %d)", k, s->k);
+
+    bool pay = !(op == KH_OP_UNION && mode == KH_OC_SUM);
+    u64 total = 0;
+    std::vector<KhSetView> views(nsets);
+    for (int g = 0; g < nsets; ++g) {
+        views[g].keys = in[g]->n ? in[g]->keys_ptr() : nullptr;
+        views[g].counts = in[g]->counts_ptr();
+        views[g].n = in[g]->n;
+        views[g].uniform = in[g]->uniform;
+        views[g].pad = 0;
+        if (in[g]->cb || in[g]->uniform != 1) pay = true;
+        total += in[g]->n;
+    }
+    c->stat.setops++;
+    c->stat.setop_in += total;
+
+    Tmp d_hist;
+    if (hist) {
+        TMP_ALLOC(d_hist, c, 8 * (u64)hist_len);
+        HIPCHK(hipMemsetAsync(d_hist.b->p, 0, 8 * (u64)hist_len, st));
+    }
+    if (total == 0) {
+        *out = make_set(k, 0, nullptr, 0, nullptr, 0, 1);
+        if (hist) memset(hist, 0, 8 * (size_t)hist_len);
+        return KH_OK;
+    }
+    const u32 cap = W == 1 ? (pay ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_W1)
+                           : (pay ? KH_SORT_CAP_PAY_W2 : KH_SORT_CAP_W2);
+    u64 target = cap * 2 / 5;   // mean fill 40 % of LDS capacity
+    DevBuf* okeys = c->buf_alloc(kb * total);
+    DevBuf* ocnt = c->buf_alloc(4 * total);
+    struct Guard { DevBuf *a, *b; ~Guard() { buf_unref(a); buf_unref(b); } } guard{okeys, ocnt};
+    if (!okeys || !ocnt) return kh_fail(KH_E_NOMEM, "device allocation failed (set-op output of %llu keys)", (unsigned long long)total);
+
+    Tmp d_views;
+    TMP_ALLOC(d_views, c, sizeof(KhSetView) * nsets);
+    HIPCHK(hipMemcpyAsync(d_views.b->p, views.data(), sizeof(KhSetView) * nsets, hipMemcpyHostToDevice, st));
+
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        u64 nr64 = std::max<u64>(1, (total + target - 1) / target);
+        if (nr64 > 0x7fffffffull) return kh_fail(KH_E_ARG, "set operation too large for one launch");
+        const u32 nranges = (u32)nr64;
+        Tmp d_bounds, d_lb;
+        TMP_ALLOC(d_bounds, c, 8 * ((u64)nranges + 1) * nsets);
+        TMP_ALLOC(d_lb, c, 8 * (u64)nranges + 64);
+        KhLookback lb;
+        lb.desc = d_lb.as<u64>();
+        lb.ticket = reinterpret_cast<u32*>(d_lb.as<u64>() + nranges);
+        lb.err = lb.ticket + 1;
+        HIPCHK(hipMemsetAsync(d_lb.b->p, 0, 8 * (u64)nranges + 64, st));
+        if (hist && attempt) HIPCHK(hipMemsetAsync(d_hist.b->p, 0, 8 * (u64)hist_len, st));
+        c->prof_begin(KC_RANGE_BOUNDS);
+        kh_launch_range_bounds(W, d_views.as<KhSetView>(), nsets, nranges, k, d_bounds.as<u64>(), st);
+        c->prof_end();
+        c->prof_begin(KC_SETOP);
+        kh_launch_setop(W, pay, cap, d_views.as<KhSetView>(), nsets, d_bounds.as<u64>(), nranges, k, op,
+                        mode, cs, okeys->p, reinterpret_cast<u32*>(ocnt->p), lb,
+                        hist ? d_hist.as<unsigned long long>() : nullptr, hist_len, st);
+        c->prof_end();
+        HIPCHK(hipGetLastError());
+        u64 tail[2];
+        HIPCHK(hipMemcpyAsync(tail, d_lb.as<u64>() + (nranges - 1), 8 + 8, hipMemcpyDeviceToHost, st));
+        if (hist) HIPCHK(hipMemcpyAsync(hist, d_hist.b->p, 8 * (size_t)hist_len, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const u32 err = reinterpret_cast<const u32*>(&tail[1])[1];
+        if (err & KH_ERR_SPIN_TIMEOUT) return kh_fail(KH_E_INTERNAL, "look-back spin timed out in set operation");
+        if (err & KH_ERR_CAPACITY) {
+            c->stat.retries++;
+            target = std::max<u64>(16, target / 4);
+            continue;
+        }
+        const u64 n = tail[0] & ((1ull << 62) - 1);
+        buf_ref(okeys);
+        buf_ref(ocnt);
+        *out = make_set(k, n, okeys, 0, ocnt, 0, 1);
+        c->stat.setop_out += n;
+        return KH_OK;
+    }
+    return kh_fail(KH_E_CAPACITY, "set operation: a key range still overflows LDS after 8 re-plans");
+}
+
+extern "C" int kh_union_sum(kh_ctx* c, const kh_set* const* sets, int nsets, uint32_t cs, kh_set** out,
+                            uint64_t* hist, uint32_t hist_len) {
+    if (!c || !sets || !out || nsets <= 0) return kh_fail(KH_E_ARG, "kh_union_sum: bad argument");
+    if (hist && hist_len < 2) return kh_fail(KH_E_ARG, "hist_len must be >= 2");
+    if (cs < 1) return kh_fail(KH_E_ARG, "cs must be >= 1");
+    HIPCHK(hipSetDevice(c->dev));
+    for (int i = 0; i < nsets; ++i)
+        if (!sets[i]) return kh_fail(KH_E_ARG, "kh_union_sum: operand %d is NULL", i);
+    if (nsets <= KH_MAX_INPUT_SETS) {
+        std::vector<const kh_set*> in(sets, sets + nsets);
+        return run_setop(c, in, KH_OP_UNION, KH_OC_SUM, cs, out, hist, hist_len);
+    }
+    // fan-in above one launch's limit: sum groups of 64 without saturation, then sum the sums
+    std::vector<kh_set*> partial;
+    auto cleanup = [&]() { for (auto* p : partial) kh_set_free(p); };
+    for (int i = 0; i < nsets; i += KH_MAX_INPUT_SETS) {
+        const int m = std::min(KH_MAX_INPUT_SETS, nsets - i);
+        std::vector<const kh_set*> in(sets + i, sets + i + m);
+        kh_set* p = nullptr;
+        int r = run_setop(c, in, KH_OP_UNION, KH_OC_SUM, 0x7fffffffu, &p, nullptr, 0);
+        if (r != KH_OK) { cleanup(); return r; }
+        partial.push_back(p);
+    }
+    int r = kh_union_sum(c, partial.data(), (int)partial.size(), cs, out, hist, hist_len);
+    cleanup();
+    return r;
+}
+
+extern "C" int kh_simple(kh_ctx* c, const kh_set* a, const kh_set* b, int op, int mode, uint32_t cs,
+                         kh_set** out) {
+    if (!c || !a || !b || !out) return kh_fail(KH_E_ARG, "kh_simple: NULL argument");
+    if (op < KH_UNION || op > KH_COUNTERS_SUBTRACT) return kh_fail(KH_E_ARG, "unknown set operation %d", op);
+    if (mode < KH_MODE_MIN || mode > KH_MODE_RIGHT) return kh_fail(KH_E_ARG, "unknown counter mode %d", mode);
+    if (cs < 1) return kh_fail(KH_E_ARG, "cs must be >= 1");
+    HIPCHK(hipSetDevice(c->dev));
+    std::vector<const kh_set*> in{a, b};
+    return run_setop(c, in, op, mode, cs, out, nullptr, 0);
+}
+
+// ------------------------------------------------------------------------------ histogram
+extern "C" int kh_histogram(kh_ctx* c, const kh_set* s, uint64_t* hist, uint32_t hist_len) {
+    if (!c || !s || !hist || hist_len < 2) return kh_fail(KH_E_ARG, "kh_histogram: bad argument");
+    HIPCHK(hipSetDevice(c->dev));
+    memset(hist, 0, 8 * (size_t)hist_len);
+    if (!s->n) return KH_OK;
+    if (!s->cb) {
+        hist[std::min<u32>(s->uniform, hist_len - 1)] = s->n;
+        return KH_OK;
+    }
+    Tmp d_hist;
+    TMP_ALLOC(d_hist, c, 8 * (u64)hist_len);
+    HIPCHK(hipMemsetAsync(d_hist.b->p, 0, 8 * (u64)hist_len, c->st));
+    c->prof_begin(KC_HISTOGRAM);
+    kh_launch_histogram(s->counts_ptr(), s->n, d_hist.as<unsigned long long>(), hist_len, c->st);
+    c->prof_end();
+    HIPCHK(hipMemcpyAsync(hist, d_hist.b->p, 8 * (size_t)hist_len, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return KH_OK;
+}
+
+// ------------------------------------------------------------------------------ transfer
+extern "C" int kh_set_download(kh_ctx* c, const kh_set* s, uint64_t* keys, uint32_t* counts) {
+    if (!c || !s) return kh_fail(KH_E_ARG, "kh_set_download: NULL argument");
+    HIPCHK(hipSetDevice(c->dev));
+    if (!s->n) return KH_OK;
+    const size_t kb = 8 * (size_t)s->W;
+    if (keys) {
+        Tmp d_tmp;
+        TMP_ALLOC(d_tmp, c, kb * s->n);
+        c->prof_begin(KC_REMIX);
+        kh_launch_unmix(s->W, s->keys_ptr(), d_tmp.b->p, s->n, s->k, c->st);
+        c->prof_end();
+        HIPCHK(hipMemcpyAsync(keys, d_tmp.b->p, kb * s->n, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(hipStreamSynchronize(c->st));
+    }
+    if (counts) {
+        if (s->cb) {
+            HIPCHK(hipMemcpyAsync(counts, s->counts_ptr(), 4 * s->n, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(hipStreamSynchronize(c->st));
+        } else {
+            std::fill(counts, counts + s->n, s->uniform);
+        }
+    }
+    return KH_OK;
+}
+
+int kh_set_from_mixed_host(kh_ctx* c, int k, u64 n, const void* keys_mixed_sorted, const u32* counts,
+                           u32 uniform, kh_set** out) {
+    const int W = k <= 32 ? 1 : 2;
+    const size_t kb = 8 * (size_t)W;
+    if (!n) { *out = make_set(k, 0, nullptr, 0, nullptr, 0, uniform); return KH_OK; }
+    DevBuf* kbuf = c->buf_alloc(kb * n);
+    DevBuf* cbuf = counts ? c->buf_alloc(4 * n) : nullptr;
+    struct Guard { DevBuf *a, *b; ~Guard() { buf_unref(a); buf_unref(b); } } guard{kbuf, cbuf};
+    if (!kbuf || (counts && !cbuf)) return kh_fail(KH_E_NOMEM, "device allocation failed (upload)");
+    HIPCHK(hipMemcpyAsync(kbuf->p, keys_mixed_sorted, kb * n, hipMemcpyHostToDevice, c->st));
+    if (counts) HIPCHK(hipMemcpyAsync(cbuf->p, counts, 4 * n, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    buf_ref(kbuf);
+    if (cbuf) buf_ref(cbuf);
+    *out = make_set(k, n, kbuf, 0, cbuf, 0, uniform);
+    return KH_OK;
+}
+
+extern "C" int kh_set_upload(kh_ctx* c, int k, uint64_t n, const uint64_t* keys, const uint32_t* counts,
+                             kh_set** out) {
+    if (!c || !out || (n && !keys)) return kh_fail(KH_E_ARG, "kh_set_upload: bad argument");
+    KHCHK(check_k(k));
+    HIPCHK(hipSetDevice(c->dev));
+    const int W = k <= 32 ? 1 : 2;
+    // order by mixed key on the host (upload is a test / interchange path, not the hot path)
+    std::vector<u64> mixed((size_t)n * W);
+    for (u64 i = 0; i < n; ++i) kh_mix_host(k, keys + i * W, mixed.data() + i * W);
+    std::vector<u64> idx(n);
+    for (u64 i = 0; i < n; ++i) idx[i] = i;
+    if (W == 1)
+        std::sort(idx.begin(), idx.end(), [&](u64 a, u64 b) { return mixed[a] < mixed[b]; });
+    else
+        std::sort(idx.begin(), idx.end(), [&](u64 a, u64 b) {
+            return mixed[2 * a + 1] < mixed[2 * b + 1] ||
+                   (mixed[2 * a + 1] == mixed[2 * b + 1] && mixed[2 * a] < mixed[2 * b]);
+        });
+    std::vector<u64> sk((size_t)n * W);
+    std::vector<u32> sc(counts ? n : 0);
+    for (u64 i = 0; i < n; ++i) {
+        for (int w = 0; w < W; ++w) sk[i * W + w] = mixed[idx[i] * W + w];
+        if (counts) sc[i] = counts[idx[i]];
+        if (i && memcmp(&sk[i * W], &sk[(i - 1) * W], 8 * W) == 0)
+            return kh_fail(KH_E_ARG, "kh_set_upload: keys are not distinct");
+    }
+    return kh_set_from_mixed_host(c, k, n, sk.data(), counts ? sc.data() : nullptr, 1, out);
+}
+
+extern "C" int kh_set_from_device(kh_ctx* c, int k, uint64_t n, const void* keys_mixed, const uint32_t* counts,
+                                  kh_set** out) {
+    if (!c || !out || (n && !keys_mixed)) return kh_fail(KH_E_ARG, "kh_set_from_device: bad argument");
+    KHCHK(check_k(k));
+    HIPCHK(hipSetDevice(c->dev));
+    const int W = k <= 32 ? 1 : 2;
+    const size_t kb = 8 * (size_t)W;
+    if (!n) { *out = make_set(k, 0, nullptr, 0, nullptr, 0, 1); return KH_OK; }
+    DevBuf* kbuf = c->buf_alloc(kb * n);
+    DevBuf* cbuf = counts ? c->buf_alloc(4 * n) : nullptr;
+    struct Guard { DevBuf *a, *b; ~Guard() { buf_unref(a); buf_unref(b); } } guard{kbuf, cbuf};
+    if (!kbuf || (counts && !cbuf)) return kh_fail(KH_E_NOMEM, "device allocation failed");
+    HIPCHK(hipMemcpyAsync(kbuf->p, keys_mixed, kb * n, hipMemcpyDeviceToDevice, c->st));
+    if (counts) HIPCHK(hipMemcpyAsync(cbuf->p, counts, 4 * n, hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    buf_ref(kbuf);
+    if (cbuf) buf_ref(cbuf);
+    *out = make_set(k, n, kbuf, 0, cbuf, 0, 1);
+    return KH_OK;
+}
+
+extern "C" int kh_set_partition_bounds(kh_ctx* c, const kh_set* s, uint32_t nparts, uint64_t* bounds) {
+    if (!c || !s || !bounds || !nparts) return kh_fail(KH_E_ARG, "kh_set_partition_bounds: bad argument");
+    HIPCHK(hipSetDevice(c->dev));
+    if (!s->n) { for (u32 i = 0; i <= nparts; ++i) bounds[i] = 0; return KH_OK; }
+    KhSetView v{s->keys_ptr(), nullptr, s->n, 1, 0};
+    Tmp d_view, d_bounds;
+    TMP_ALLOC(d_view, c, sizeof v);
+    TMP_ALLOC(d_bounds, c, 8 * ((u64)nparts + 1));
+    HIPCHK(hipMemcpyAsync(d_view.b->p, &v, sizeof v, hipMemcpyHostToDevice, c->st));
+    kh_launch_range_bounds(s->W, d_view.as<KhSetView>(), 1, nparts, s->k, d_bounds.as<u64>(), c->st);
+    HIPCHK(hipMemcpyAsync(bounds, d_bounds.b->p, 8 * ((u64)nparts + 1), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return KH_OK;
+}
+
+// ------------------------------------------------------------------------------ fused exp 1
+extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
+                           int on_device, const int* group_of, int ngroups, int k, uint32_t cs,
+                           uint64_t* within_hist, uint64_t* across_hist, uint32_t hist_len,
+                           uint64_t* distinct_per_seq, kh_set** group_sets, kh_set** across_set) {
+    if (!c || !seqs || !lens || !group_of || nseq <= 0 || ngroups <= 0)
+        return kh_fail(KH_E_ARG, "kh_exp1_run: bad argument");
+    if ((within_hist || across_hist) && hist_len < 2) return kh_fail(KH_E_ARG, "hist_len must be >= 2");
+    for (int i = 0; i < nseq; ++i)
+        if (group_of[i] < 0 || group_of[i] >= ngroups)
+            return kh_fail(KH_E_ARG, "group_of[%d]=%d outside [0,%d)", i, group_of[i], ngroups);
+    std::vector<kh_set*> gsets(nseq, nullptr), unions(ngroups, nullptr), usets(ngroups, nullptr);
+    kh_set* across = nullptr;
+    auto cleanup = [&]() {
+        for (auto* s : gsets) kh_set_free(s);
+        for (auto* s : unions) kh_set_free(s);
+        for (auto* s : usets) kh_set_free(s);
+        kh_set_free(across);
+    };
+    // steps 1+2: build every genome as a plain set
+    int r = kh_build_batch(c, nseq, seqs, lens, on_device, k, 1, KH_NO_MAX, KH_KMC_DEFAULT_CS, 0, gsets.data());
+    if (r != KH_OK) { cleanup(); return r; }
+    if (distinct_per_seq)
+        for (int i = 0; i < nseq; ++i) distinct_per_seq[i] = gsets[i]->n;
+    // steps 3+4 per group, step 6
+    for (int g = 0; g < ngroups; ++g) {
+        std::vector<const kh_set*> members;
+        for (int i = 0; i < nseq; ++i)
+            if (group_of[i] == g) members.push_back(gsets[i]);
+        if (members.empty()) { cleanup(); return kh_fail(KH_E_ARG, "group %d has no sequences", g); }
+        r = kh_union_sum(c, members.data(), (int)members.size(), cs, &unions[g],
+                         within_hist ? within_hist + (size_t)g * hist_len : nullptr, hist_len);
+        if (r != KH_OK) { cleanup(); return r; }
+        r = kh_set_counts(c, unions[g], 1, &usets[g]);
+        if (r != KH_OK) { cleanup(); return r; }
+    }
+    // steps 7+8
+    r = kh_union_sum(c, usets.data(), ngroups, cs, &across, across_hist, hist_len);
+    if (r != KH_OK) { cleanup(); return r; }
+    if (group_sets)
+        for (int g = 0; g < ngroups; ++g) { group_sets[g] = unions[g]; unions[g] = nullptr; }
+    if (across_set) { *across_set = across; across = nullptr; }
+    cleanup();
+    return KH_OK;
+}
+
+// ------------------------------------------------------------------------------ host mix
+extern "C" void kh_mix_host(int k, const uint64_t* in, uint64_t* out) {
+    if (k <= 32) {
+        KmerKey<1> a{in[0]};
+        a = kh_mix(a, k);
+        out[0] = a.lo;
+    } else {
+        KmerKey<2> a{in[0], in[1]};
+        a = kh_mix(a, k);
+        out[0] = a.lo;
+        out[1] = a.hi;
+    }
+}
+extern "C" void kh_unmix_host(int k, const uint64_t* in, uint64_t* out) {
+    if (k <= 32) {
+        KmerKey<1> a{in[0]};
+        a = kh_unmix(a, k);
+        out[0] = a.lo;
+    } else {
+        KmerKey<2> a{in[0], in[1]};
+        a = kh_unmix(a, k);
+        out[0] = a.lo;
+        out[1] = a.hi;
+    }
+}

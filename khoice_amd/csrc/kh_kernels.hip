@@ -1,0 +1,857 @@
+// khoice_amd — hand-written gfx950 (CDNA4, wave64) kernels for the k-mer hot path.
+//
+// Pipeline of one batched build (K1; replaces `kmc -fm -k{k} -ci1`, reference call site
+// workflow/rules/exp_type_1.smk:163):
+//   pass A  k_extract<W,false>   bases -> canonical k-mer -> mixed key -> per-tile bucket histogram
+//           k_col_totals / k_exscan / k_col_offsets      bucket starts and per-tile write cursors
+//   pass B  k_extract<W,true>    same extraction, keys scattered to their bucket (LDS cursors)
+//   pass C  k_bucket_sort_rle<W> one workgroup per bucket: LDS bitonic sort, run-length count,
+//                                ordered single-pass output (decoupled look-back)
+// Set operations (K3/K5/K6; `kmc_tools complex|simple`, exp_type_1.smk:182, exp_type_2.smk:363-379):
+//   k_range_bounds<W>            binary-search the slot boundaries of every operand
+//   k_setop<W,PAY>               one workgroup per slot: gather operand slices into LDS, sort,
+//                                combine counters per key, fused counter histogram (K4),
+//                                ordered single-pass output
+// All integer work; bounded by HBM bandwidth, not by MFMA (none is used).
+#include <hip/hip_runtime.h>
+#include "kh_launch.h"
+
+#define KH_WAVE 64
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & (KH_WAVE - 1); }
+
+// rank of this thread among flagged threads of the block (exclusive) and the block total.
+// wave_tot: LDS scratch of blockDim/64 words.  Contains two barriers.
+__device__ __forceinline__ u32 block_rank(bool flag, u32* wave_tot, u32& total) {
+    const u64 b = __ballot(flag);
+    const u32 lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) wave_tot[wid] = (u32)__popcll(b);
+    __syncthreads();
+    u32 pre = 0, tot = 0;
+    for (u32 w = 0; w < nw; ++w) {
+        const u32 v = wave_tot[w];
+        pre += (w < wid) ? v : 0u;
+        tot += v;
+    }
+    __syncthreads();
+    total = tot;
+    return pre + (u32)__popcll(b & ((1ull << lane) - 1ull));
+}
+
+// ---- ordered single-pass output: decoupled look-back over 64-bit {status:2, value:62} words.
+// One 8-byte relaxed agent-scope store/load carries status and value together, so no
+// separate flag ordering is needed.  Tickets are handed out in start order, hence every
+// predecessor of a resident workgroup is resident or finished: no deadlock.  Spins are
+// bounded; on timeout an error bit is raised and the launch drains.
+constexpr u64 KH_LB_AGG = 1ull << 62;
+constexpr u64 KH_LB_PREFIX = 2ull << 62;
+constexpr u64 KH_LB_VALUE = (1ull << 62) - 1ull;
+
+__device__ __forceinline__ void lb_store(u64* p, u64 v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 lb_load(u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by the 64 lanes of wave 0.  Publishes `mine`, returns the exclusive prefix.
+__device__ u64 lookback_wave(u64* desc, u32 q, u64 mine, u32* err) {
+    const u32 lane = lane_id();
+    if (q == 0) {
+        if (lane == 0) lb_store(&desc[0], KH_LB_PREFIX | mine);
+        return 0;
+    }
+    if (lane == 0) lb_store(&desc[q], KH_LB_AGG | mine);
+    u64 excl = 0;
+    long long base = (long long)q - 1;
+    bool timed_out = false;
+    while (true) {
+        const long long idx = base - (long long)lane;
+        u64 d = KH_LB_PREFIX;   // "before the first part": prefix 0
+        if (idx >= 0) {
+            d = lb_load(&desc[idx]);
+            u32 spins = 0;
+            while ((d >> 62) == 0) {
+                __builtin_amdgcn_s_sleep(2);
+                d = lb_load(&desc[idx]);
+                if (++spins > (1u << 22)) { timed_out = true; d = KH_LB_PREFIX; break; }
+            }
+        }
+        const u64 is_prefix = __ballot((d >> 62) == 2);
+        u64 v = d & KH_LB_VALUE;
+        if (is_prefix) {
+            const u32 first = (u32)__ffsll((unsigned long long)is_prefix) - 1u;
+            v = (lane <= first) ? v : 0ull;
+        }
+        // wave sum of v
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        excl += v;
+        if (is_prefix) break;
+        base -= KH_WAVE;
+    }
+    if (__ballot(timed_out) && lane == 0) atomicOr(err, KH_ERR_SPIN_TIMEOUT);
+    if (lane == 0) lb_store(&desc[q], KH_LB_PREFIX | ((excl + mine) & KH_LB_VALUE));
+    return excl;
+}
+
+// ------------------------------------------------------------------------------------------
+// pass A / pass B: base decoding, rolling canonical k-mer, mixing, bucket histogram / scatter
+// ------------------------------------------------------------------------------------------
+constexpr int KH_HALO = 64;                                   // k-1 <= 63 extra bases
+constexpr int KH_CODE_WORDS = (KH_SUBTILE + KH_HALO) / 16;    // 516 words of 16 bases
+
+size_t kh_extract_lds_bytes(u32 nb_alloc) {
+    return (size_t)nb_alloc * 4 + (size_t)KH_CODE_WORDS * 4 + (size_t)KH_CODE_WORDS * 2 + 16;
+}
+
+// 16 ASCII bases -> 16 two-bit codes + 16 "not ACGTacgt" flags.
+__device__ __forceinline__ void decode16(const uint4 v, u32& codes, u32& bad) {
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+    codes = 0;
+    bad = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const u32 c = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+        const u32 up = c & 0xdfu;                              // fold case
+        const u32 code = ((c >> 1) ^ (c >> 2)) & 3u;            // A0 C1 G2 T3
+        const bool ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+        codes |= code << (2 * i);
+        bad |= (ok ? 0u : 1u) << i;
+    }
+}
+
+template <int W> struct Roller;
+template <> struct Roller<1> {
+    u64 mask, top_shift;
+    __device__ Roller(int k) : mask(kh_mask(2 * k)), top_shift(2 * k - 2) {}
+    __device__ __forceinline__ void push(KmerKey<1>& f, KmerKey<1>& r, u32 c) const {
+        f.lo = ((f.lo << 2) | c) & mask;
+        r.lo = (r.lo >> 2) | ((u64)(3u - c) << top_shift);
+    }
+};
+template <> struct Roller<2> {
+    u64 mask_hi, top_shift;   // hi holds 2k-64 bits
+    __device__ Roller(int k) : mask_hi(kh_mask(2 * k - 64)), top_shift(2 * k - 64 - 2) {}
+    __device__ __forceinline__ void push(KmerKey<2>& f, KmerKey<2>& r, u32 c) const {
+        f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
+        f.lo = (f.lo << 2) | c;
+        r.lo = (r.lo >> 2) | (r.hi << 62);
+        r.hi = (r.hi >> 2) | ((u64)(3u - c) << top_shift);
+    }
+};
+template <int W> __device__ __forceinline__ KmerKey<W> key_zero();
+template <> __device__ __forceinline__ KmerKey<1> key_zero<1>() { return KmerKey<1>{0}; }
+template <> __device__ __forceinline__ KmerKey<2> key_zero<2>() { return KmerKey<2>{0, 0}; }
+
+template <int W, bool SCATTER>
+__global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
+                                                const KhSeg* __restrict__ segs,
+                                                const KhTile* __restrict__ tiles, u32 nb_alloc,
+                                                int k, u32* __restrict__ thist,
+                                                const u64* __restrict__ bstart,
+                                                KmerKey<W>* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    u32* cur = reinterpret_cast<u32*>(lds_raw);
+    u32* code = cur + nb_alloc;
+    u16* bad16 = reinterpret_cast<u16*>(code + KH_CODE_WORDS);
+
+    const u32 tid = threadIdx.x;
+    const KhTile t = tiles[blockIdx.x];
+    const KhSeg sg = segs[t.seg];
+    const u32 nb = sg.nbuckets;
+    u32* row = thist + sg.thist_base + (u64)t.tile_in_seg * nb;
+
+    for (u32 i = tid; i < nb; i += 256) cur[i] = SCATTER ? row[i] : 0u;
+    u64 part_base = 0;
+    if (SCATTER) part_base = bstart[sg.bucket_base];
+
+    const Roller<W> roller(k);
+    const u8* sbase = seq + sg.seq_off;
+    const u64 tile_pos0 = (u64)t.tile_in_seg * KH_TILE;
+
+    for (int sub = 0; sub < KH_SUBTILES_PER_TILE; ++sub) {
+        const u64 p0 = tile_pos0 + (u64)sub * KH_SUBTILE;
+        if (p0 >= sg.npos) break;   // uniform over the block
+        __syncthreads();            // cursor init done / previous sub-tile fully consumed
+        for (u32 w = tid; w < (u32)KH_CODE_WORDS; w += 256) {
+            const u64 b0 = p0 + 16ull * w;
+            u32 codes = 0, bad = 0xffffu;
+            if (b0 < sg.len) {
+                const uint4 v = *reinterpret_cast<const uint4*>(sbase + b0);
+                decode16(v, codes, bad);
+                const u64 left = sg.len - b0;
+                if (left < 16) bad |= (0xffffu << (u32)left) & 0xffffu;
+            }
+            code[w] = codes;
+            bad16[w] = (u16)bad;
+        }
+        __syncthreads();
+        // thread handles start positions 32*tid .. 32*tid+31 of this sub-tile; it needs
+        // bases 32*tid .. 32*tid + 30 + k, i.e. at most 6 code words.
+        KmerKey<W> f = key_zero<W>(), r = key_zero<W>();
+        int run = 0;
+        const int last_base = 31 + k - 1;   // index (relative to 32*tid) of the last base needed
+        for (int wi = 0; wi * 16 <= last_base; ++wi) {
+            const u32 cw = code[2 * tid + wi];
+            const u32 bw = bad16[2 * tid + wi];
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int u = wi * 16 + j;
+                const u32 c = (cw >> (2 * j)) & 3u;
+                roller.push(f, r, c);
+                run = ((bw >> j) & 1u) ? 0 : run + 1;
+                const int st = u - (k - 1);
+                if (st >= 0 && st < 32 && run >= k) {
+                    KmerKey<W> can = key_lt(r, f) ? r : f;
+                    can = kh_mix(can, k);
+                    const u32 slot = kh_slot<W>(can, k, nb);
+                    if (SCATTER) {
+                        const u32 pos = atomicAdd(&cur[slot], 1u);
+                        part[part_base + pos] = can;
+                    } else {
+                        atomicAdd(&cur[slot], 1u);
+                    }
+                }
+            }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (u32 i = tid; i < nb; i += 256) row[i] = cur[i];
+    }
+}
+
+// column totals of the (tile x bucket) histogram matrix: one thread per (segment, bucket)
+__global__ void k_col_totals(const KhSeg* __restrict__ segs, const u32* __restrict__ thist,
+                             u64* __restrict__ tot) {
+    const KhSeg sg = segs[blockIdx.y];
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= sg.nbuckets) return;
+    u64 s = 0;
+    for (u32 t = 0; t < sg.ntiles; ++t) s += thist[sg.thist_base + (u64)t * sg.nbuckets + b];
+    tot[sg.bucket_base + b] = s;
+}
+// turn per-tile counts into per-tile write cursors, relative to the segment's first bucket
+__global__ void k_col_offsets(const KhSeg* __restrict__ segs, u32* __restrict__ thist,
+                              const u64* __restrict__ bstart) {
+    const KhSeg sg = segs[blockIdx.y];
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= sg.nbuckets) return;
+    u64 running = bstart[sg.bucket_base + b] - bstart[sg.bucket_base];
+    for (u32 t = 0; t < sg.ntiles; ++t) {
+        const u64 at = sg.thist_base + (u64)t * sg.nbuckets + b;
+        const u32 c = thist[at];
+        thist[at] = (u32)running;
+        running += c;
+    }
+}
+
+// exclusive scan of n u64 values by one 1024-thread block; out[n] = total.
+__global__ __launch_bounds__(1024) void k_exscan(const u64* __restrict__ in, u64* __restrict__ out,
+                                                 u64 n) {
+    __shared__ u64 part[1024];
+    const u32 tid = threadIdx.x;
+    const u64 chunk = (n + 1023) / 1024;
+    const u64 lo = (u64)tid * chunk;
+    const u64 hi = lo + chunk < n ? lo + chunk : n;
+    u64 s = 0;
+    for (u64 i = lo; i < hi; ++i) s += in[i];
+    part[tid] = s;
+    __syncthreads();
+    for (u32 off = 1; off < 1024; off <<= 1) {
+        u64 v = 0;
+        if (tid >= off) v = part[tid - off];
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u64 run = part[tid] - s;   // exclusive prefix of this thread's chunk
+    for (u64 i = lo; i < hi; ++i) {
+        const u64 v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (tid == 1023) out[n] = part[1023];
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS bitonic sort (keys, optional 32-bit payload) of s[0..n), any n.
+// All comparators put the smaller key at the lower index (the "flip" form of the network:
+// the first step of every merge stage compares mirrored elements).  Indices >= n stand for
+// +infinity keys; such an element can never move, so a comparator touching one is skipped
+// and no padding (or sentinel key value) is needed.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 next_pow2(u32 v) {
+    u32 p = 2;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+template <int W, bool PAY>
+__device__ __forceinline__ void cmp_exchange(KmerKey<W>* s, u32* pay, u32 i, u32 j) {
+    const KmerKey<W> a = s[i], b = s[j];
+    if (key_lt(b, a)) {
+        s[i] = b;
+        s[j] = a;
+        if (PAY) {
+            const u32 pa = pay[i];
+            pay[i] = pay[j];
+            pay[j] = pa;
+        }
+    }
+}
+
+template <int W, bool PAY>
+__device__ void bitonic_sort_lds(KmerKey<W>* s, u32* pay, const u32 n) {
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    if (n < 2) return;
+    const u32 P = next_pow2(n);
+    for (u32 size = 2; size <= P; size <<= 1) {
+        const u32 half = size >> 1;
+        for (u32 t = tid; t < (P >> 1); t += nt) {
+            const u32 off = t & (half - 1);
+            const u32 blk = (t & ~(half - 1)) << 1;
+            const u32 i = blk | off, j = blk + size - 1 - off;
+            if (j < n) cmp_exchange<W, PAY>(s, pay, i, j);
+        }
+        __syncthreads();
+        for (u32 stride = size >> 2; stride > 0; stride >>= 1) {
+            for (u32 t = tid; t < (P >> 1); t += nt) {
+                const u32 i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                const u32 j = i | stride;
+                if (j < n) cmp_exchange<W, PAY>(s, pay, i, j);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Mark run heads of the sorted keys s[0..n) and record their start indices:
+// hstart[r] = index of the r-th distinct key, hstart[d] = n.  Returns d (block-uniform).
+template <int W>
+__device__ u32 find_runs(const KmerKey<W>* s, u32 n, u16* hstart, u32* wave_tot) {
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    u32 base = 0;
+    for (u32 i0 = 0; i0 < n; i0 += nt) {
+        const u32 i = i0 + tid;
+        const bool head = (i < n) && (i == 0 || !key_eq(s[i], s[i - 1]));
+        u32 tot;
+        const u32 rk = block_rank(head, wave_tot, tot);
+        if (head) hstart[base + rk] = (u16)i;
+        base += tot;
+    }
+    if (tid == 0) hstart[base] = (u16)n;
+    __syncthreads();
+    return base;
+}
+
+// LDS carve shared by k_bucket_sort_rle and k_setop (everything lives in dynamic LDS so that
+// its base stays 16-B aligned):  keys[cap] | pay[cap] (optional) | hstart[cap+2] u16 |
+// lhist[KH_LHIST_BINS] | scratch[32] u32 | bcast[4] u64
+struct SortLds {
+    u8* base;
+    u32 cap;
+    int W;
+    bool pay;
+    __host__ __device__ size_t keys_off() const { return 0; }
+    __host__ __device__ size_t pay_off() const { return (size_t)cap * 8 * W; }
+    __host__ __device__ size_t hstart_off() const { return pay_off() + (pay ? (size_t)cap * 4 : 0); }
+    __host__ __device__ size_t lhist_off() const {
+        return (hstart_off() + ((size_t)cap + 2) * 2 + 15) & ~(size_t)15;
+    }
+    __host__ __device__ size_t scratch_off() const { return lhist_off() + KH_LHIST_BINS * 4; }
+    __host__ __device__ size_t bcast_off() const { return scratch_off() + 32 * 4; }
+    __host__ __device__ size_t total() const { return bcast_off() + 4 * 8; }
+};
+size_t kh_sort_lds_bytes(int W, u32 cap, bool pay) {
+    SortLds L{nullptr, cap, W, pay};
+    return L.total();
+}
+
+// ------------------------------------------------------------------------------------------
+// pass C: per-bucket sort + run-length count + ordered output
+// ------------------------------------------------------------------------------------------
+// Normal buckets (n <= cap): keys-only sort, counter = run length.
+// Oversize buckets (duplicate-heavy input, e.g. small k or low-complexity sequence): the
+// same LDS is re-carved as (key, counter) pairs of half the capacity and the bucket is
+// folded in chunks: [accumulated distinct pairs | next raw chunk] -> sort -> sum per key.
+// Only a bucket with more DISTINCT keys than the pair capacity cannot be handled; that
+// raises KH_ERR_CAPACITY (the host then re-runs the segment with more buckets).
+template <int W>
+__global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
+    const KmerKey<W>* __restrict__ part, const u64* __restrict__ bstart, u32 cap, int k,
+    KmerKey<W>* __restrict__ out_keys, u32* __restrict__ out_counts, KhLookback lb, u32 ci, u32 cx,
+    u32 cs) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    const SortLds L{lds_raw, cap, W, false};
+    KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
+    u16* hstart = reinterpret_cast<u16*>(lds_raw + L.hstart_off());
+    u32* scratch = reinterpret_cast<u32*>(lds_raw + L.scratch_off());
+    u64* bcast = reinterpret_cast<u64*>(lds_raw + L.bcast_off());
+    // pair-mode carve (oversize path): keys[capp] | pay[capp] inside the key region;
+    // hstart is reused as is (capp < cap).
+    const u32 capp = ((cap * 8u * W) / (8u * W + 4u)) & ~63u;
+    u32* pay = reinterpret_cast<u32*>(lds_raw + (size_t)capp * 8 * W);
+
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
+    __syncthreads();
+    const u32 q = scratch[16];
+    const u64 lo = bstart[q], hi = bstart[q + 1];
+    const u64 n64 = hi - lo;
+    const bool filt = (ci > 1u) || (cx != 0xffffffffu);
+
+    u32 d = 0;            // distinct keys now in LDS
+    bool pairs = false;   // counters live in pay[] (else: run lengths via hstart)
+    bool fail = false;
+
+    if (n64 <= cap) {
+        const u32 n = (u32)n64;
+        for (u32 i = tid; i < n; i += nt) s[i] = part[lo + i];
+        __syncthreads();
+        bitonic_sort_lds<W, false>(s, nullptr, n);
+        d = find_runs<W>(s, n, hstart, scratch);
+    } else {
+        pairs = true;
+        u32 acc = 0;
+        u64 consumed = 0;
+        while (consumed < n64) {
+            if (acc >= capp) { fail = true; break; }
+            const u64 left = n64 - consumed;
+            const u32 take = left < (u64)(capp - acc) ? (u32)left : (capp - acc);
+            const u32 m = acc + take;
+            for (u32 i = acc + tid; i < m; i += nt) {
+                s[i] = part[lo + consumed + (i - acc)];
+                pay[i] = 1u;
+            }
+            __syncthreads();
+            bitonic_sort_lds<W, true>(s, pay, m);
+            const u32 dd = find_runs<W>(s, m, hstart, scratch);
+            // fold runs in place: slot r <- (key, saturating sum of payloads)
+            for (u32 r0 = 0; r0 < dd; r0 += nt) {
+                const u32 r = r0 + tid;
+                KmerKey<W> kv = key_zero<W>();
+                u64 sum = 0;
+                if (r < dd) {
+                    const u32 h0 = hstart[r], h1 = hstart[r + 1];
+                    kv = s[h0];
+                    for (u32 j = h0; j < h1; ++j) sum += pay[j];
+                    if (sum > 0xffffffffull) sum = 0xffffffffull;
+                }
+                __syncthreads();
+                if (r < dd) { s[r] = kv; pay[r] = (u32)sum; }
+                __syncthreads();
+            }
+            acc = dd;
+            consumed += take;
+        }
+        d = acc;
+    }
+    if (fail) {
+        if (tid == 0) atomicOr(lb.err, KH_ERR_CAPACITY);
+        d = 0;
+    }
+
+    // counter of output r and whether it survives -ci/-cx
+    auto counter = [&](u32 r) -> u32 {
+        return pairs ? pay[r] : (u32)(hstart[r + 1] - hstart[r]);
+    };
+    u32 dk = d;
+    if (filt) {
+        u32 mine = 0;
+        for (u32 r = tid; r < d; r += nt) {
+            const u32 c = counter(r);
+            mine += (c >= ci && c <= cx) ? 1u : 0u;
+        }
+        // block sum through ballot-free LDS reduction
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+        if (lane_id() == 0) scratch[tid >> 6] = mine;
+        __syncthreads();
+        dk = 0;
+        for (u32 w = 0; w < (nt >> 6); ++w) dk += scratch[w];
+        __syncthreads();
+    }
+
+    if (tid < KH_WAVE) {
+        const u64 excl = lookback_wave(lb.desc, q, (u64)dk, lb.err);
+        if (tid == 0) bcast[0] = excl;
+    }
+    __syncthreads();
+    const u64 obase = bcast[0];
+
+    u32 running = 0;
+    for (u32 r0 = 0; r0 < d; r0 += nt) {
+        const u32 r = r0 + tid;
+        u32 c = 0;
+        bool keep = false;
+        if (r < d) {
+            c = counter(r);
+            keep = !filt || (c >= ci && c <= cx);
+        }
+        u32 tot;
+        const u32 rk = block_rank(keep, scratch, tot);
+        if (keep) {
+            const u64 o = obase + running + rk;
+            out_keys[o] = pairs ? s[r] : s[hstart[r]];
+            if (out_counts) out_counts[o] = c < cs ? c : cs;
+        }
+        running += tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// set operations on sorted sets
+// ------------------------------------------------------------------------------------------
+// bounds[g * (nranges + 1) + r] = first index of set g whose key falls in slot >= r
+template <int W>
+__global__ void k_range_bounds(const KhSetView* __restrict__ sets, u32 nsets, u32 nranges, int k,
+                               u64* __restrict__ bounds) {
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 per = (u64)nranges + 1;
+    if (idx >= per * nsets) return;
+    const u32 g = (u32)(idx / per), r = (u32)(idx % per);
+    const KhSetView sv = sets[g];
+    const KmerKey<W>* keys = reinterpret_cast<const KmerKey<W>*>(sv.keys);
+    u64 lo = 0, hi = sv.n;
+    if (r == 0) hi = 0;
+    if (r >= nranges) lo = hi;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (kh_slot<W>(keys[mid], k, nranges) < r) lo = mid + 1; else hi = mid;
+    }
+    bounds[idx] = lo;
+}
+
+__device__ __forceinline__ long long combine_counters(int mode, long long a, long long b) {
+    switch (mode) {
+        case KH_OC_MIN: return a < b ? a : b;
+        case KH_OC_MAX: return a > b ? a : b;
+        case KH_OC_SUM: return a + b;
+        case KH_OC_DIFF: return a - b;
+        case KH_OC_LEFT: return a;
+        default: return b;
+    }
+}
+
+// PAY=false: n-ary union of sets whose counters are all 1, counters summed: the counter of a
+// key is simply the length of its run, no payload array needed (the step_3 / step_7 case,
+// exp_type_1.smk:182,250).  PAY=true: payload = counter | (operand index > 0) << 31.
+template <int W, bool PAY>
+__global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
+    const KhSetView* __restrict__ sets, u32 nsets, const u64* __restrict__ bounds, u32 nranges,
+    u32 cap, int k, int op, int mode, u32 cs, KmerKey<W>* __restrict__ out_keys,
+    u32* __restrict__ out_counts, KhLookback lb, unsigned long long* __restrict__ hist,
+    u32 hist_len) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    const SortLds L{lds_raw, cap, W, PAY};
+    KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
+    u32* pay = reinterpret_cast<u32*>(lds_raw + L.pay_off());
+    u16* hstart = reinterpret_cast<u16*>(lds_raw + L.hstart_off());
+    u32* lhist = reinterpret_cast<u32*>(lds_raw + L.lhist_off());
+    u32* scratch = reinterpret_cast<u32*>(lds_raw + L.scratch_off());
+    u64* bcast = reinterpret_cast<u64*>(lds_raw + L.bcast_off());
+    // slice offsets of the operands inside LDS: reuse the head of hstart's successor region
+    // is not safe, so keep them in lhist until the gather is done (nsets <= 64 < bins)
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
+    __syncthreads();
+    const u32 q = scratch[16];
+    const u64 per = (u64)nranges + 1;
+
+    if (tid == 0) {
+        u64 tot = 0;
+        for (u32 g = 0; g < nsets; ++g) {
+            lhist[g] = (u32)(tot > 0xffffffffull ? 0xffffffffull : tot);
+            tot += bounds[g * per + q + 1] - bounds[g * per + q];
+        }
+        bcast[1] = tot;
+    }
+    __syncthreads();
+    const u64 n64 = bcast[1];
+    u32 n = 0;
+    if (n64 > cap) {
+        if (tid == 0) atomicOr(lb.err, KH_ERR_CAPACITY);
+    } else {
+        n = (u32)n64;
+    }
+    if (n) {
+        for (u32 g = 0; g < nsets; ++g) {
+            const KhSetView sv = sets[g];
+            const u64 b0 = bounds[g * per + q], b1 = bounds[g * per + q + 1];
+            const u32 off = lhist[g];
+            const KmerKey<W>* keys = reinterpret_cast<const KmerKey<W>*>(sv.keys);
+            for (u64 i = tid; i < b1 - b0; i += nt) {
+                s[off + i] = keys[b0 + i];
+                if (PAY) {
+                    u32 c = sv.counts ? sv.counts[b0 + i] : sv.uniform;
+                    if (c > 0x7fffffffu) c = 0x7fffffffu;
+                    // binary operations tag the second operand; n-ary unions only ever sum
+                    pay[off + i] = c | ((nsets == 2 && g == 1) ? 0x80000000u : 0u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < KH_LHIST_BINS; i += nt) lhist[i] = 0;
+    __syncthreads();
+    bitonic_sort_lds<W, PAY>(s, pay, n);
+    const u32 d = n ? find_runs<W>(s, n, hstart, scratch) : 0u;
+
+    // evaluate run r: returns counter (0 = dropped)
+    auto eval = [&](u32 r) -> u32 {
+        const u32 h0 = hstart[r], h1 = hstart[r + 1];
+        long long c;
+        if (!PAY) {
+            c = (long long)(h1 - h0);
+        } else {
+            long long ca = 0, cb = 0;
+            bool ha = false, hb = false;
+            for (u32 j = h0; j < h1; ++j) {
+                const u32 p = pay[j];
+                if (p >> 31) { cb += p & 0x7fffffffu; hb = true; } else { ca += p; ha = true; }
+            }
+            switch (op) {
+                case KH_OP_UNION:
+                    c = (ha && hb) ? combine_counters(mode, ca, cb) : (ca + cb);
+                    break;
+                case KH_OP_INTERSECT:
+                    c = (ha && hb) ? combine_counters(mode, ca, cb) : 0;
+                    break;
+                case KH_OP_KMERS_SUBTRACT:
+                    c = (ha && !hb) ? ca : 0;
+                    break;
+                default:   // counters subtract
+                    c = ha ? ca - cb : 0;
+                    break;
+            }
+        }
+        if (c <= 0) return 0u;
+        return c > (long long)cs ? cs : (u32)c;
+    };
+
+    // pass 1: how many keys survive (needed before the look-back)
+    u32 mine = 0;
+    for (u32 r = tid; r < d; r += nt) mine += eval(r) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane_id() == 0) scratch[tid >> 6] = mine;
+    __syncthreads();
+    u32 dk = 0;
+    for (u32 w = 0; w < (nt >> 6); ++w) dk += scratch[w];
+    __syncthreads();
+
+    if (tid < KH_WAVE) {
+        const u64 excl = lookback_wave(lb.desc, q, (u64)dk, lb.err);
+        if (tid == 0) bcast[0] = excl;
+    }
+    __syncthreads();
+    const u64 obase = bcast[0];
+
+    u32 running = 0;
+    for (u32 r0 = 0; r0 < d; r0 += nt) {
+        const u32 r = r0 + tid;
+        const u32 c = (r < d) ? eval(r) : 0u;
+        const bool keep = c != 0;
+        u32 tot;
+        const u32 rk = block_rank(keep, scratch, tot);
+        if (keep) {
+            const u64 o = obase + running + rk;
+            out_keys[o] = s[hstart[r]];
+            if (out_counts) out_counts[o] = c;
+            if (hist) {
+                if (c < KH_LHIST_BINS) atomicAdd(&lhist[c], 1u);
+                else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
+            }
+        }
+        running += tot;
+    }
+    if (hist) {
+        __syncthreads();
+        for (u32 i = tid; i < KH_LHIST_BINS; i += nt) {
+            const u32 v = lhist[i];
+            if (v) atomicAdd(&hist[i < hist_len ? i : hist_len - 1], (unsigned long long)v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_histogram(const u32* __restrict__ counts, u64 n,
+                                                  unsigned long long* __restrict__ hist,
+                                                  u32 hist_len) {
+    __shared__ u32 lh[KH_LHIST_BINS];
+    for (u32 i = threadIdx.x; i < KH_LHIST_BINS; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u32 c = counts[i];
+        if (c < KH_LHIST_BINS) atomicAdd(&lh[c], 1u);
+        else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < KH_LHIST_BINS; i += blockDim.x) {
+        const u32 v = lh[i];
+        if (v) atomicAdd(&hist[i < hist_len ? i : hist_len - 1], (unsigned long long)v);
+    }
+}
+
+template <int W, bool UNMIX>
+__global__ void k_remix(const KmerKey<W>* __restrict__ in, KmerKey<W>* __restrict__ out, u64 n,
+                        int k) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = UNMIX ? kh_unmix(in[i], k) : kh_mix(in[i], k);
+}
+
+__global__ void k_fill_u32(u32* __restrict__ p, u64 n, u32 v) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+__global__ void k_clamp_u32(const u32* __restrict__ in, u32* __restrict__ out, u64 n, u32 cs) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u32 v = in[i];
+        out[i] = v < cs ? v : cs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static u32 grid_for(u64 n, u32 block, u32 cap_blocks = 2048) {
+    u64 g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap_blocks) g = cap_blocks;
+    return (u32)g;
+}
+
+template <class K> static void allow_lds(K kern, size_t bytes) {
+    static thread_local size_t granted = 0;   // per kernel instantiation
+    if (bytes > 48 * 1024 && bytes > granted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        granted = bytes;
+    }
+}
+
+void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, const KhTile* tiles,
+                       u32 ntiles, u32 nb_alloc, int k, u32* thist, const u64* bstart, void* part,
+                       hipStream_t st) {
+    if (!ntiles) return;
+    const size_t lds = kh_extract_lds_bytes(nb_alloc);
+#define KH_EX(WW, SC)                                                                           \
+    do {                                                                                        \
+        allow_lds(k_extract<WW, SC>, lds);                                                      \
+        hipLaunchKernelGGL((k_extract<WW, SC>), dim3(ntiles), dim3(256), lds, st, seq, segs,    \
+                           tiles, nb_alloc, k, thist, bstart,                                   \
+                           reinterpret_cast<KmerKey<WW>*>(part));                               \
+    } while (0)
+    if (W == 1) { if (scatter) KH_EX(1, true); else KH_EX(1, false); }
+    else        { if (scatter) KH_EX(2, true); else KH_EX(2, false); }
+#undef KH_EX
+}
+
+void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* thist, u64* tot,
+                          hipStream_t st) {
+    if (!nseg || !max_nb) return;
+    hipLaunchKernelGGL(k_col_totals, dim3((max_nb + 255) / 256, nseg), dim3(256), 0, st, segs,
+                       thist, tot);
+}
+void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
+                           hipStream_t st) {
+    if (!nseg || !max_nb) return;
+    hipLaunchKernelGGL(k_col_offsets, dim3((max_nb + 255) / 256, nseg), dim3(256), 0, st, segs,
+                       thist, bstart);
+}
+void kh_launch_exscan(const u64* in, u64* out, u64 n, hipStream_t st) {
+    hipLaunchKernelGGL(k_exscan, dim3(1), dim3(1024), 0, st, in, out, n);
+}
+
+void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, u32 nbuckets, int k,
+                           void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
+                           hipStream_t st) {
+    if (!nbuckets) return;
+    const u32 cap = W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2;
+    const size_t lds = kh_sort_lds_bytes(W, cap, false);
+    if (W == 1) {
+        allow_lds(k_bucket_sort_rle<1>, lds);
+        hipLaunchKernelGGL((k_bucket_sort_rle<1>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
+                           reinterpret_cast<const KmerKey<1>*>(part), bstart, cap, k,
+                           reinterpret_cast<KmerKey<1>*>(out_keys), out_counts, lb, ci, cx, cs);
+    } else {
+        allow_lds(k_bucket_sort_rle<2>, lds);
+        hipLaunchKernelGGL((k_bucket_sort_rle<2>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
+                           reinterpret_cast<const KmerKey<2>*>(part), bstart, cap, k,
+                           reinterpret_cast<KmerKey<2>*>(out_keys), out_counts, lb, ci, cx, cs);
+    }
+}
+
+void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges, int k,
+                            u64* bounds, hipStream_t st) {
+    const u64 total = ((u64)nranges + 1) * nsets;
+    const u32 grid = (u32)((total + 255) / 256);
+    if (W == 1)
+        hipLaunchKernelGGL((k_range_bounds<1>), dim3(grid), dim3(256), 0, st, sets, nsets, nranges,
+                           k, bounds);
+    else
+        hipLaunchKernelGGL((k_range_bounds<2>), dim3(grid), dim3(256), 0, st, sets, nsets, nranges,
+                           k, bounds);
+}
+
+void kh_launch_setop(int W, bool pay, u32 cap, const KhSetView* sets, u32 nsets, const u64* bounds,
+                     u32 nranges, int k, int op, int mode, u32 cs, void* out_keys, u32* out_counts,
+                     KhLookback lb, unsigned long long* hist, u32 hist_len, hipStream_t st) {
+    if (!nranges) return;
+    const size_t lds = kh_sort_lds_bytes(W, cap, pay);
+#define KH_SO(WW, PP)                                                                            \
+    do {                                                                                         \
+        allow_lds(k_setop<WW, PP>, lds);                                                         \
+        hipLaunchKernelGGL((k_setop<WW, PP>), dim3(nranges), dim3(KH_SORT_THREADS), lds, st,     \
+                           sets, nsets, bounds, nranges, cap, k, op, mode, cs,                   \
+                           reinterpret_cast<KmerKey<WW>*>(out_keys), out_counts, lb, hist,       \
+                           hist_len);                                                            \
+    } while (0)
+    if (W == 1) { if (pay) KH_SO(1, true); else KH_SO(1, false); }
+    else        { if (pay) KH_SO(2, true); else KH_SO(2, false); }
+#undef KH_SO
+}
+
+void kh_launch_histogram(const u32* counts, u64 n, unsigned long long* hist, u32 hist_len,
+                         hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_histogram, dim3(grid_for(n, 256 * 8)), dim3(256), 0, st, counts, n, hist,
+                       hist_len);
+}
+void kh_launch_unmix(int W, const void* in, void* out, u64 n, int k, hipStream_t st) {
+    if (!n) return;
+    if (W == 1)
+        hipLaunchKernelGGL((k_remix<1, true>), dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const KmerKey<1>*>(in),
+                           reinterpret_cast<KmerKey<1>*>(out), n, k);
+    else
+        hipLaunchKernelGGL((k_remix<2, true>), dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const KmerKey<2>*>(in),
+                           reinterpret_cast<KmerKey<2>*>(out), n, k);
+}
+void kh_launch_mix(int W, const void* in, void* out, u64 n, int k, hipStream_t st) {
+    if (!n) return;
+    if (W == 1)
+        hipLaunchKernelGGL((k_remix<1, false>), dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const KmerKey<1>*>(in),
+                           reinterpret_cast<KmerKey<1>*>(out), n, k);
+    else
+        hipLaunchKernelGGL((k_remix<2, false>), dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const KmerKey<2>*>(in),
+                           reinterpret_cast<KmerKey<2>*>(out), n, k);
+}
+void kh_launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n, 256)), dim3(256), 0, st, p, n, v);
+}
+void kh_launch_clamp_u32(const u32* in, u32* out, u64 n, u32 cs, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_clamp_u32, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, n, cs);
+}

@@ -1,0 +1,58 @@
+// Host-callable launchers for the gfx950 kernels in kh_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kh_common.h"
+
+// one input sequence (genome) of a batched build
+struct KhSeg {
+    u64 seq_off;      // byte offset of base 0 in the batch sequence buffer (16-B aligned)
+    u64 len;          // bases (bytes)
+    u64 npos;         // k-mer start positions: len >= k ? len-k+1 : 0
+    u64 thist_base;   // index of tile 0 / bucket 0 in the tile-histogram matrix
+    u32 nbuckets;     // B_s
+    u32 bucket_base;  // index of its first bucket in the global bucket arrays
+    u32 tile_base;    // global index of its first tile
+    u32 ntiles;
+};
+struct KhTile { u32 seg; u32 tile_in_seg; };
+
+struct KhSetView {    // one operand of a set operation (device-resident, sorted by mixed key)
+    const void* keys;
+    const u32* counts;   // nullptr => every counter == uniform
+    u64 n;
+    u32 uniform;
+    u32 pad;
+};
+
+struct KhLookback {      // workspace of one ordered single-pass launch
+    u64* desc;           // [nparts] tile descriptors, zeroed before launch
+    u32* ticket;         // zeroed before launch
+    u32* err;            // sticky error bits
+};
+enum : u32 { KH_ERR_SPIN_TIMEOUT = 1u, KH_ERR_CAPACITY = 2u };
+
+size_t kh_extract_lds_bytes(u32 nb_alloc);
+size_t kh_sort_lds_bytes(int W, u32 cap, bool pay);
+
+void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, const KhTile* tiles,
+                       u32 ntiles, u32 nb_alloc, int k, u32* thist, const u64* bstart, void* part,
+                       hipStream_t st);
+void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* thist, u64* tot,
+                          hipStream_t st);
+void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
+                           hipStream_t st);
+void kh_launch_exscan(const u64* in, u64* out, u64 n, hipStream_t st);   // out has n+1 entries
+void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, u32 nbuckets, int k,
+                           void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
+                           hipStream_t st);
+void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges, int k,
+                            u64* bounds, hipStream_t st);
+void kh_launch_setop(int W, bool pay, u32 cap, const KhSetView* sets, u32 nsets, const u64* bounds,
+                     u32 nranges, int k, int op, int mode, u32 cs, void* out_keys, u32* out_counts,
+                     KhLookback lb, unsigned long long* hist, u32 hist_len, hipStream_t st);
+void kh_launch_histogram(const u32* counts, u64 n, unsigned long long* hist, u32 hist_len,
+                         hipStream_t st);
+void kh_launch_unmix(int W, const void* in, void* out, u64 n, int k, hipStream_t st);
+void kh_launch_mix(int W, const void* in, void* out, u64 n, int k, hipStream_t st);
+void kh_launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st);
+void kh_launch_clamp_u32(const u32* in, u32* out, u64 n, u32 cs, hipStream_t st);
