@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py — distinct canonical k-mers / second of the khoice experiment-type-1 hot path.
+
+One step = the whole device side of workflow/rules/exp_type_1.smk:156-259 for k = 31 over a
+synthetic 10-species x 5-genome x 5 Mbp set (BASELINE.json north_star / SURVEY.md §8d
+"Headline"): per genome build + set (steps 1-2), per group union-sum + histogram
+(steps 3-4), group sets (step 6), across-group union-sum + histogram (steps 7-8).
+Inputs (cleaned sequence text, 1 byte per base) are resident in HBM before the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU; every rank owns its own 10 species (weak scaling); steps 1-6 need
+no communication, step 7-8 exchanges the group sets by key range over RCCL (all-to-all) and
+all-reduces the histogram (khoice_amd/dist.py).
+
+value = (sum over all genomes of all ranks of their distinct canonical k-mers) / step time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--species", type=int, default=10)
+    ap.add_argument("--genomes", type=int, default=5)
+    ap.add_argument("--length", type=int, default=5_000_000)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-species", type=int, default=4)
+    return ap.parse_args()
+
+
+def kernel_algorithmic_bytes(name, st, k, nseq_bases):
+    """Compulsory HBM bytes of ONE launch of a kernel class (read every input once, write
+    every output once), from the engine's own counters for the timed steps."""
+    w = 1 if k <= 32 else 2
+    kb = 8 * w
+    launches = max(1, st["kernels"][name]["launches"])
+    steps_bases = st["bases"]
+    kmers, distinct = st["kmers"], st["distinct"]
+    if name == "extract_hist":
+        total = steps_bases
+    elif name == "extract_scatter":
+        total = steps_bases + kmers * kb
+    elif name == "bucket_sort_rle":
+        total = kmers * kb + distinct * kb           # plain sets: no counter array written
+    elif name == "setop":
+        total = st["setop_in"] * kb + st["setop_out"] * (kb + 4)
+    else:
+        total = 0
+    return total / launches
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch
+    import torch.distributed as dist
+
+    from khoice_amd import engine as E
+    from khoice_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; khoice_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic inputs, resident in HBM
+    t0 = time.time()
+    items = synth.species_set(args.species, args.genomes, args.length,
+                              first_species=1 + rank * args.species)
+    group_of = [s - 1 - rank * args.species for s, _, _ in items]
+    host = [np.frombuffer(t, dtype=np.uint8) for _, _, t in items]
+    dev = [torch.from_numpy(h.copy()).cuda() for h in host]
+    seqs = [(d.data_ptr(), d.numel()) for d in dev]
+    total_bases = sum(d.numel() for d in dev)
+    gen_s = time.time() - t0
+
+    eng = E.Engine(local_rank)
+    if world > 1:
+        from khoice_amd import dist as kdist
+
+    def step():
+        if world == 1:
+            return eng.exp1_run(seqs, group_of, args.k, cs=5000, hist_len=5001)
+        return kdist.exp1_step(eng, seqs, group_of, args.k, cs=5000, hist_len=5001)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    eng.stats_reset()
+    eng.profile(True)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t1
+    st = eng.stats()          # collects the HIP events recorded on the engine's stream
+    eng.profile(False)
+
+    distinct_local = int(res["distinct_per_seq"].sum())
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        dd = torch.tensor([distinct_local], device="cuda", dtype=torch.int64)
+        dist.all_reduce(dd, op=dist.ReduceOp.SUM)
+        distinct_all = int(dd.item())
+    else:
+        distinct_all = distinct_local
+    ms_per_step = 1e3 * dt / args.steps
+    value = distinct_all / (dt / args.steps)
+
+    # ---- roofline of the dominant kernel (HIP events on the engine's stream)
+    kern = st["kernels"]
+    hot = max((n for n in kern if n not in ("copy_in",)), key=lambda n: kern[n]["ms"])
+    avg_ms = kern[hot]["ms"] / max(1, kern[hot]["launches"])
+    alg_bytes = kernel_algorithmic_bytes(hot, st, args.k, total_bases)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(hot, {}).get("bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": hot, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)}
+    # whole K1 build against SURVEY §8d's compulsory figure N*1 + D*(8W+4)
+    w = 1 if args.k <= 32 else 2
+    k1_ms = sum(kern[n]["ms"] for n in ("extract_hist", "bucket_plan", "extract_scatter", "bucket_sort_rle"))
+    k1_bytes = st["bases"] + st["distinct"] * (8 * w + 4)
+    kernel_ms = {n: round(v["ms"] / args.steps, 4) for n, v in kern.items()}
+
+    out = {
+        "metric": "distinct k-mers/sec (k=31, canonical)" if args.k == 31 else f"distinct k-mers/sec (k={args.k}, canonical)",
+        "value": round(value, 1), "unit": "distinct k-mers/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64" if args.k <= 32 else "u128",
+        "data": "synthetic",
+        "config": {"workload": f"exp_type_1 steps 1-8: {args.species} species x {args.genomes} genomes x "
+                               f"{args.length} bp per GPU, k={args.k}, cs=5000",
+                   "species_per_gpu": args.species, "genomes_per_species": args.genomes,
+                   "genome_bp": args.length, "k": args.k, "bases_per_gpu": total_bases,
+                   "distinct_kmers_per_step": distinct_all, "sharding": f"groups x{world}"},
+        "roofline": roofline,
+        "k1_build_roofline": {"algorithmic_bytes": int(k1_bytes / args.steps),
+                              "ms": round(k1_ms / args.steps, 4),
+                              "achieved": round(k1_bytes / (k1_ms * 1e-3) / 1e9, 1) if k1_ms else 0.0,
+                              "frac": round(k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k1_ms else 0.0,
+                              "unit": "GB/s"},
+        "kernel_ms_per_step": kernel_ms,
+        "setup_seconds": round(gen_s, 1),
+    }
+
+    # ---- CPU baseline: the C restatement on a bounded sample of the same workload
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle as CO
+        ns = min(args.cpu_species, args.species)
+        sample = [(s, g, t) for s, g, t in items if s - 1 - rank * args.species < ns]
+        cseqs = [t for _, _, t in sample]
+        cgroup = [s - 1 - rank * args.species for s, _, _ in sample]
+        cores = min(os.cpu_count() or 1, len(cseqs))
+        c0 = time.perf_counter()
+        cres = CO.exp1(cseqs, cgroup, args.k, cs=5000, hist_len=5001, nthreads=cores)
+        cdt = time.perf_counter() - c0
+        cd = int(cres["distinct_per_seq"].sum())
+        ok = bool((cres["within_hist"] == res["within_hist"][:ns]).all())
+        out["cpu_baseline"] = {"value": round(cd / cdt, 1), "unit": "distinct k-mers/s",
+                               "cores": int(cres["threads"]), "kind": "port",
+                               "sample": f"{ns} species x {args.genomes} genomes x {args.length} bp of the same "
+                                         f"set, oracle/kh_oracle.c kho_exp1, {cdt:.1f} s",
+                               "within_hist_equal_to_gpu": ok}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
