@@ -386,7 +386,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     lb.err = lb.ticket + 1;
     HIPCHK(hipMemsetAsync(d_lb.b->p, 0, 8 * (u64)nb_total + 64, st));
     c->prof_begin(KC_BUCKET_SORT);
-    kh_launch_bucket_sort(W, d_part.b->p, d_bstart.as<u64>(), nb_total, k, okeys->p,
+    kh_launch_bucket_sort(W, d_part.b->p, d_bstart.as<u64>(), d_segs.as<KhSeg>(), (u32)nseq, nb_total, k, okeys->p,
                           ocnt ? reinterpret_cast<u32*>(ocnt->p) : nullptr, lb, ci, cx, cs, st);
     c->prof_end();
     HIPCHK(hipGetLastError());

@@ -349,8 +349,9 @@ __device__ u32 find_runs(const KmerKey<W>* s, u32 n, u16* hstart, u32* wave_tot)
 }
 
 // LDS carve shared by k_bucket_sort_rle and k_setop (everything lives in dynamic LDS so that
-// its base stays 16-B aligned):  keys[cap] | pay[cap] (optional) | hstart[cap+2] u16 |
-// lhist[KH_LHIST_BINS] | scratch[32] u32 | bcast[4] u64
+// its base stays 16-B aligned):  keys[cap] | pay[cap] (optional) | aux | lhist[KH_LHIST_BINS] |
+// scratch[32] u32 | bcast[4] u64, where aux holds the fine-bin table bins[KH_FINE_BINS+1] u32
+// while sorting and hstart[cap+2] u16 afterwards.
 struct SortLds {
     u8* base;
     u32 cap;
@@ -360,7 +361,9 @@ struct SortLds {
     __host__ __device__ size_t pay_off() const { return (size_t)cap * 8 * W; }
     __host__ __device__ size_t hstart_off() const { return pay_off() + (pay ? (size_t)cap * 4 : 0); }
     __host__ __device__ size_t lhist_off() const {
-        return (hstart_off() + ((size_t)cap + 2) * 2 + 15) & ~(size_t)15;
+        size_t aux = ((size_t)cap + 2) * 2;
+        if (aux < (size_t)(KH_FINE_BINS + 1) * 4) aux = (size_t)(KH_FINE_BINS + 1) * 4;
+        return (hstart_off() + aux + 15) & ~(size_t)15;
     }
     __host__ __device__ size_t scratch_off() const { return lhist_off() + KH_LHIST_BINS * 4; }
     __host__ __device__ size_t bcast_off() const { return scratch_off() + 32 * 4; }
@@ -369,6 +372,111 @@ struct SortLds {
 size_t kh_sort_lds_bytes(int W, u32 cap, bool pay) {
     SortLds L{nullptr, cap, W, pay};
     return L.total();
+}
+
+// ------------------------------------------------------------------------------------------
+// Distribution sort of one slot's keys, from registers into LDS.
+// Mixed keys are uniform inside a slot, so one counting pass over KH_FINE_BINS order-preserving
+// fine bins (about one key per bin) leaves the array sorted up to tiny per-bin permutations,
+// which one insertion pass per thread removes.  About 20x less LDS traffic than sorting the
+// slot with the bitonic network.  Equal keys land in one bin and cost O(run) to pass over;
+// only a bin crowded with DISTINCT keys would be slow, so a block whose fullest bin exceeds
+// KH_FINE_LIMIT falls back to the bitonic network (always correct).
+//   kreg/preg : this thread's keys (element e*NT + tid) and payloads
+//   bins      : LDS u32[KH_FINE_BINS + 1] (aliases hstart, which is only used afterwards)
+// ------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ u32 fine_bin(const KmerKey<W>& key, int k, u32 nslots) {
+    const u32 frac = (u32)((u64)kh_top32(key, k) * (u64)nslots);   // position inside the slot
+    return frac >> (32 - KH_FINE_BITS);
+}
+
+template <int W, bool PAY, int E>
+__device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E], const u32 n,
+                                KmerKey<W>* s, u32* pay, u32* bins, u32* scratch, int k,
+                                u32 nslots) {
+    constexpr u32 NT = KH_SORT_THREADS;
+    constexpr u32 PER = KH_FINE_BINS / NT;   // bins scanned per thread
+    const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    for (u32 i = tid; i <= (u32)KH_FINE_BINS; i += NT) bins[i] = 0;
+    __syncthreads();
+    u32 fr[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        fr[e] = 0;
+        if ((u32)e * NT + tid < n) {
+            const u32 f = fine_bin<W>(kreg[e], k, nslots);
+            fr[e] = (f << 16) | atomicAdd(&bins[f], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bin counts (PER consecutive bins per thread) + fullest bin
+    u32 c[PER], sum = 0, mx = 0;
+#pragma unroll
+    for (u32 j = 0; j < PER; ++j) {
+        c[j] = bins[tid * PER + j];
+        mx = c[j] > mx ? c[j] : mx;
+        sum += c[j];
+    }
+    u32 incl = sum;
+#pragma unroll
+    for (int off = 1; off < KH_WAVE; off <<= 1) {
+        const u32 u = __shfl_up(incl, off);
+        if (lane >= (u32)off) incl += u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u32 o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == KH_WAVE - 1) scratch[wid] = incl;
+    if (lane == 0) scratch[8 + wid] = mx;
+    __syncthreads();
+    u32 wbase = 0, bmax = 0;
+#pragma unroll
+    for (u32 w = 0; w < NT / KH_WAVE; ++w) {
+        wbase += (w < wid) ? scratch[w] : 0u;
+        bmax = scratch[8 + w] > bmax ? scratch[8 + w] : bmax;
+    }
+    u32 run = wbase + incl - sum;
+#pragma unroll
+    for (u32 j = 0; j < PER; ++j) {
+        bins[tid * PER + j] = run;
+        run += c[j];
+    }
+    if (tid == NT - 1) bins[KH_FINE_BINS] = run;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if ((u32)e * NT + tid < n) {
+            const u32 at = bins[fr[e] >> 16] + (fr[e] & 0xffffu);
+            s[at] = kreg[e];
+            if (PAY) pay[at] = preg[e];
+        }
+    }
+    __syncthreads();
+    if (bmax > (u32)KH_FINE_LIMIT) {
+        bitonic_sort_lds<W, PAY>(s, pay, n);
+        return;
+    }
+    // insertion pass over this thread's PER consecutive bins (elements never leave their bin)
+    const u32 lo = bins[tid * PER], hi = bins[tid * PER + PER];
+    for (u32 i = lo + 1; i < hi; ++i) {
+        const KmerKey<W> key = s[i];
+        u32 pv = 0;
+        if (PAY) pv = pay[i];
+        u32 j = i;
+        while (j > lo && key_lt(key, s[j - 1])) {
+            s[j] = s[j - 1];
+            if (PAY) pay[j] = pay[j - 1];
+            --j;
+        }
+        if (j != i) {
+            s[j] = key;
+            if (PAY) pay[j] = pv;
+        }
+    }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -382,9 +490,9 @@ size_t kh_sort_lds_bytes(int W, u32 cap, bool pay) {
 // raises KH_ERR_CAPACITY (the host then re-runs the segment with more buckets).
 template <int W>
 __global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
-    const KmerKey<W>* __restrict__ part, const u64* __restrict__ bstart, u32 cap, int k,
-    KmerKey<W>* __restrict__ out_keys, u32* __restrict__ out_counts, KhLookback lb, u32 ci, u32 cx,
-    u32 cs) {
+    const KmerKey<W>* __restrict__ part, const u64* __restrict__ bstart,
+    const KhSeg* __restrict__ segs, u32 nseg, u32 cap, int k, KmerKey<W>* __restrict__ out_keys,
+    u32* __restrict__ out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     const SortLds L{lds_raw, cap, W, false};
     KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
@@ -397,9 +505,20 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
     u32* pay = reinterpret_cast<u32*>(lds_raw + (size_t)capp * 8 * W);
 
     const u32 tid = threadIdx.x, nt = blockDim.x;
-    if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
+    if (tid == 0) {
+        const u32 t = atomicAdd(lb.ticket, 1u);
+        scratch[16] = t;
+        // owning segment of global bucket t: last segment with bucket_base <= t
+        u32 a = 0, b = nseg;
+        while (b - a > 1) {
+            const u32 m = (a + b) >> 1;
+            if (segs[m].bucket_base <= t) a = m; else b = m;
+        }
+        scratch[17] = segs[a].nbuckets;
+    }
     __syncthreads();
     const u32 q = scratch[16];
+    const u32 seg_nb = scratch[17];
     const u64 lo = bstart[q], hi = bstart[q + 1];
     const u64 n64 = hi - lo;
     const bool filt = (ci > 1u) || (cx != 0xffffffffu);
@@ -410,9 +529,18 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
 
     if (n64 <= cap) {
         const u32 n = (u32)n64;
-        for (u32 i = tid; i < n; i += nt) s[i] = part[lo + i];
-        __syncthreads();
-        bitonic_sort_lds<W, false>(s, nullptr, n);
+        constexpr int E = (W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2) / KH_SORT_THREADS;
+        KmerKey<W> kreg[E];
+        u32 preg[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            preg[e] = 0;
+            kreg[e] = key_zero<W>();
+            const u32 i = (u32)e * KH_SORT_THREADS + tid;
+            if (i < n) kreg[e] = part[lo + i];
+        }
+        distribute_sort<W, false, E>(kreg, preg, n, s, nullptr, reinterpret_cast<u32*>(hstart),
+                                     scratch, k, seg_nb);
         d = find_runs<W>(s, n, hstart, scratch);
     } else {
         pairs = true;
@@ -553,8 +681,13 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
     u32* lhist = reinterpret_cast<u32*>(lds_raw + L.lhist_off());
     u32* scratch = reinterpret_cast<u32*>(lds_raw + L.scratch_off());
     u64* bcast = reinterpret_cast<u64*>(lds_raw + L.bcast_off());
-    // slice offsets of the operands inside LDS: reuse the head of hstart's successor region
-    // is not safe, so keep them in lhist until the gather is done (nsets <= 64 < bins)
+    // while gathering, lhist holds the operand slices: soff[g] = first LDS index of slice g
+    // (words 0..63) and sbeg[g] = first element of the slice inside operand g (words 64..191)
+    constexpr int CAPC = PAY ? (W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2)
+                             : (W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2);
+    constexpr int E = (CAPC + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
+    u32* soff = lhist;
+    u64* sbeg = reinterpret_cast<u64*>(lhist + 64);
     const u32 tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
     __syncthreads();
@@ -564,40 +697,49 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
     if (tid == 0) {
         u64 tot = 0;
         for (u32 g = 0; g < nsets; ++g) {
-            lhist[g] = (u32)(tot > 0xffffffffull ? 0xffffffffull : tot);
-            tot += bounds[g * per + q + 1] - bounds[g * per + q];
+            const u64 b0 = bounds[g * per + q], b1 = bounds[g * per + q + 1];
+            soff[g] = (u32)(tot > 0xffffffffull ? 0xffffffffull : tot);
+            sbeg[g] = b0;
+            tot += b1 - b0;
         }
         bcast[1] = tot;
     }
     __syncthreads();
     const u64 n64 = bcast[1];
     u32 n = 0;
-    if (n64 > cap) {
+    if (n64 > (u64)CAPC || n64 > (u64)cap) {
         if (tid == 0) atomicOr(lb.err, KH_ERR_CAPACITY);
     } else {
         n = (u32)n64;
     }
-    if (n) {
-        for (u32 g = 0; g < nsets; ++g) {
-            const KhSetView sv = sets[g];
-            const u64 b0 = bounds[g * per + q], b1 = bounds[g * per + q + 1];
-            const u32 off = lhist[g];
-            const KmerKey<W>* keys = reinterpret_cast<const KmerKey<W>*>(sv.keys);
-            for (u64 i = tid; i < b1 - b0; i += nt) {
-                s[off + i] = keys[b0 + i];
-                if (PAY) {
-                    u32 c = sv.counts ? sv.counts[b0 + i] : sv.uniform;
-                    if (c > 0x7fffffffu) c = 0x7fffffffu;
-                    // binary operations tag the second operand; n-ary unions only ever sum
-                    pay[off + i] = c | ((nsets == 2 && g == 1) ? 0x80000000u : 0u);
-                }
+    KmerKey<W> kreg[E];
+    u32 preg[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        kreg[e] = key_zero<W>();
+        preg[e] = 0;
+        const u32 i = (u32)e * KH_SORT_THREADS + tid;
+        if (i < n) {
+            u32 ga = 0, gb = nsets;          // last operand whose slice starts at or before i
+            while (gb - ga > 1) {
+                const u32 m = (ga + gb) >> 1;
+                if (soff[m] <= i) ga = m; else gb = m;
+            }
+            const KhSetView sv = sets[ga];
+            const u64 idx = sbeg[ga] + (i - soff[ga]);
+            kreg[e] = reinterpret_cast<const KmerKey<W>*>(sv.keys)[idx];
+            if (PAY) {
+                u32 c = sv.counts ? sv.counts[idx] : sv.uniform;
+                if (c > 0x7fffffffu) c = 0x7fffffffu;
+                // binary operations tag the second operand; n-ary unions only ever sum
+                preg[e] = c | ((nsets == 2 && ga == 1) ? 0x80000000u : 0u);
             }
         }
     }
     __syncthreads();
     for (u32 i = tid; i < KH_LHIST_BINS; i += nt) lhist[i] = 0;
-    __syncthreads();
-    bitonic_sort_lds<W, PAY>(s, pay, n);
+    distribute_sort<W, PAY, E>(kreg, preg, n, s, pay, reinterpret_cast<u32*>(hstart), scratch, k,
+                               nranges);
     const u32 d = n ? find_runs<W>(s, n, hstart, scratch) : 0u;
 
     // evaluate run r: returns counter (0 = dropped)
@@ -770,21 +912,21 @@ void kh_launch_exscan(const u64* in, u64* out, u64 n, hipStream_t st) {
     hipLaunchKernelGGL(k_exscan, dim3(1), dim3(1024), 0, st, in, out, n);
 }
 
-void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, u32 nbuckets, int k,
-                           void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
-                           hipStream_t st) {
+void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const KhSeg* segs, u32 nseg,
+                           u32 nbuckets, int k, void* out_keys, u32* out_counts, KhLookback lb,
+                           u32 ci, u32 cx, u32 cs, hipStream_t st) {
     if (!nbuckets) return;
     const u32 cap = W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2;
     const size_t lds = kh_sort_lds_bytes(W, cap, false);
     if (W == 1) {
         allow_lds(k_bucket_sort_rle<1>, lds);
         hipLaunchKernelGGL((k_bucket_sort_rle<1>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
-                           reinterpret_cast<const KmerKey<1>*>(part), bstart, cap, k,
+                           reinterpret_cast<const KmerKey<1>*>(part), bstart, segs, nseg, cap, k,
                            reinterpret_cast<KmerKey<1>*>(out_keys), out_counts, lb, ci, cx, cs);
     } else {
         allow_lds(k_bucket_sort_rle<2>, lds);
         hipLaunchKernelGGL((k_bucket_sort_rle<2>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
-                           reinterpret_cast<const KmerKey<2>*>(part), bstart, cap, k,
+                           reinterpret_cast<const KmerKey<2>*>(part), bstart, segs, nseg, cap, k,
                            reinterpret_cast<KmerKey<2>*>(out_keys), out_counts, lb, ci, cx, cs);
     }
 }

@@ -42,7 +42,8 @@ void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* th
 void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
                            hipStream_t st);
 void kh_launch_exscan(const u64* in, u64* out, u64 n, hipStream_t st);   // out has n+1 entries
-void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, u32 nbuckets, int k,
+void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const KhSeg* segs, u32 nseg,
+                           u32 nbuckets, int k,
                            void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
                            hipStream_t st);
 void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges, int k,
