@@ -133,10 +133,12 @@ constexpr int KH_TILE = KH_SUBTILE * KH_SUBTILES_PER_TILE;
 constexpr int KH_MAX_BUCKETS_PER_SEG = 16384;   // LDS cursor array limit (64 KiB)
 constexpr int KH_BUCKET_MEAN_W1 = 3400;     // target keys per bucket (typical P = 4096)
 constexpr int KH_BUCKET_MEAN_W2 = 1700;
-constexpr int KH_SORT_CAP_W1 = 7168;        // LDS sort capacity in keys (56 KiB of keys, 2 WG/CU)
-constexpr int KH_SORT_CAP_W2 = 3584;
-constexpr int KH_SORT_CAP_PAY_W1 = 4736;    // capacity with a 32-bit payload per key
-constexpr int KH_SORT_CAP_PAY_W2 = 2816;
+// LDS sort capacity in keys.  Mixed keys make slot sizes Poisson-tight (mean 3400 -> sigma 58),
+// so 4096 leaves 12 sigma; 8 keys per thread keep the unrolled per-thread arrays in <128 VGPRs.
+constexpr int KH_SORT_CAP_W1 = 4096;
+constexpr int KH_SORT_CAP_W2 = 2048;
+constexpr int KH_SORT_CAP_PAY_W1 = 4096;    // capacity with a 32-bit payload per key
+constexpr int KH_SORT_CAP_PAY_W2 = 2048;
 constexpr int KH_SORT_THREADS = 512;
 constexpr int KH_FINE_BITS = 12;            // fine bins of the in-LDS distribution sort
 constexpr int KH_FINE_BINS = 1 << KH_FINE_BITS;

@@ -291,6 +291,29 @@ extern "C" int kh_set_counts(kh_ctx* c, const kh_set* in, uint32_t value, kh_set
     return KH_OK;
 }
 
+#ifdef KH_STAMPS
+void kh_debug_set_stamps(u64* p);
+// diagnostic build: average shader-clock deltas between phase stamps over all workgroups
+static void report_stamps(kh_ctx* c, const char* what, DevBuf* sb, u64 nparts) {
+    std::vector<u64> h(nparts * 16);
+    (void)hipMemcpyAsync(h.data(), sb->p, nparts * 128, hipMemcpyDeviceToHost, c->st);
+    (void)hipStreamSynchronize(c->st);
+    double sum[16] = {0};
+    u64 cnt = 0, tmin = ~0ull, tmax = 0;
+    for (u64 q = 0; q < nparts; ++q) {
+        const u64* t = &h[q * 16];
+        if (!t[0] || !t[8]) continue;
+        ++cnt;
+        for (int i = 1; i <= 8; ++i) if (t[i] && t[i - 1]) sum[i] += (double)(t[i] - t[i - 1]);
+        tmin = std::min(tmin, t[0]);
+        tmax = std::max(tmax, t[8]);
+    }
+    fprintf(stderr, "[stamps] %s parts=%llu span=%.0f cyc | load %.0f count %.0f scan %.0f scatter %.0f insert %.0f walk1 %.0f lookback %.0f walk2 %.0f\n",
+            what, (unsigned long long)cnt, (double)(tmax - tmin), sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt,
+            sum[5] / cnt, sum[6] / cnt, sum[7] / cnt, sum[8] / cnt);
+}
+#endif
+
 // ------------------------------------------------------------------------------ K1 build
 static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
                       int on_device, int k, u32 ci, u32 cx, u32 cs, int with_counts, u32 mean,
@@ -385,11 +408,21 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     lb.ticket = reinterpret_cast<u32*>(d_lb.as<u64>() + nb_total);
     lb.err = lb.ticket + 1;
     HIPCHK(hipMemsetAsync(d_lb.b->p, 0, 8 * (u64)nb_total + 64, st));
+#ifdef KH_STAMPS
+    Tmp d_stamps;
+    TMP_ALLOC(d_stamps, c, 128 * (u64)nb_total);
+    HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * (u64)nb_total, st));
+    kh_debug_set_stamps(d_stamps.as<u64>());
+#endif
     c->prof_begin(KC_BUCKET_SORT);
     kh_launch_bucket_sort(W, d_part.b->p, d_bstart.as<u64>(), d_segs.as<KhSeg>(), (u32)nseq, nb_total, k, okeys->p,
                           ocnt ? reinterpret_cast<u32*>(ocnt->p) : nullptr, lb, ci, cx, cs, st);
     c->prof_end();
     HIPCHK(hipGetLastError());
+#ifdef KH_STAMPS
+    report_stamps(c, "bucket_sort", d_stamps.b, nb_total);
+    kh_debug_set_stamps(nullptr);
+#endif
 
     // ---- read back set boundaries
     std::vector<u64> desc((size_t)nb_total + 8);
@@ -474,7 +507,7 @@ static int run_setop(kh_ctx* c, const std::vector<const kh_set*>& in, int op, in
     }
     const u32 cap = W == 1 ? (pay ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_W1)
                            : (pay ? KH_SORT_CAP_PAY_W2 : KH_SORT_CAP_W2);
-    u64 target = cap * 2 / 5;   // mean fill 40 % of LDS capacity
+    u64 target = (u64)cap * 83 / 100;   // slots are Poisson-tight: mean fill 83 % of LDS capacity
     DevBuf* okeys = c->buf_alloc(kb * total);
     DevBuf* ocnt = c->buf_alloc(4 * total);
     struct Guard { DevBuf *a, *b; ~Guard() { buf_unref(a); buf_unref(b); } } guard{okeys, ocnt};
@@ -497,6 +530,12 @@ static int run_setop(kh_ctx* c, const std::vector<const kh_set*>& in, int op, in
         lb.err = lb.ticket + 1;
         HIPCHK(hipMemsetAsync(d_lb.b->p, 0, 8 * (u64)nranges + 64, st));
         if (hist && attempt) HIPCHK(hipMemsetAsync(d_hist.b->p, 0, 8 * (u64)hist_len, st));
+#ifdef KH_STAMPS
+        Tmp d_stamps;
+        TMP_ALLOC(d_stamps, c, 128 * (u64)nranges);
+        HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * (u64)nranges, st));
+        kh_debug_set_stamps(d_stamps.as<u64>());
+#endif
         c->prof_begin(KC_RANGE_BOUNDS);
         kh_launch_range_bounds(W, d_views.as<KhSetView>(), nsets, nranges, k, d_bounds.as<u64>(), st);
         c->prof_end();
@@ -506,6 +545,10 @@ static int run_setop(kh_ctx* c, const std::vector<const kh_set*>& in, int op, in
                         hist ? d_hist.as<unsigned long long>() : nullptr, hist_len, st);
         c->prof_end();
         HIPCHK(hipGetLastError());
+#ifdef KH_STAMPS
+        report_stamps(c, "setop", d_stamps.b, nranges);
+        kh_debug_set_stamps(nullptr);
+#endif
         u64 tail[2];
         HIPCHK(hipMemcpyAsync(tail, d_lb.as<u64>() + (nranges - 1), 8 + 8, hipMemcpyDeviceToHost, st));
         if (hist) HIPCHK(hipMemcpyAsync(hist, d_hist.b->p, 8 * (size_t)hist_len, hipMemcpyDeviceToHost, st));

@@ -18,6 +18,21 @@
 
 #define KH_WAVE 64
 
+// Diagnostic build only (-DKH_STAMPS, never the shipped library): thread 0 of every sort
+// workgroup stores the shader clock at phase boundaries into a buffer of its own.
+#ifdef KH_STAMPS
+__device__ u64* g_kh_stamps = nullptr;
+void kh_debug_set_stamps(u64* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kh_stamps), &p, sizeof p); }
+#define KH_STAMP(q, idx)                                                              \
+    do {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        if (threadIdx.x == 0 && g_kh_stamps) g_kh_stamps[(u64)(q) * 16 + (idx)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+    } while (0)
+#else
+#define KH_STAMP(q, idx) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
@@ -350,8 +365,8 @@ __device__ u32 find_runs(const KmerKey<W>* s, u32 n, u16* hstart, u32* wave_tot)
 
 // LDS carve shared by k_bucket_sort_rle and k_setop (everything lives in dynamic LDS so that
 // its base stays 16-B aligned):  keys[cap] | pay[cap] (optional) | aux | lhist[KH_LHIST_BINS] |
-// scratch[32] u32 | bcast[4] u64, where aux holds the fine-bin table bins[KH_FINE_BINS+1] u32
-// while sorting and hstart[cap+2] u16 afterwards.
+// tab[128] | scratch[32] u32 | bcast[4] u64, where aux holds the fine-bin table
+// bins[KH_FINE_BINS+1] u32 while sorting and hstart[cap+2] u16 afterwards.
 struct SortLds {
     u8* base;
     u32 cap;
@@ -365,7 +380,8 @@ struct SortLds {
         if (aux < (size_t)(KH_FINE_BINS + 1) * 4) aux = (size_t)(KH_FINE_BINS + 1) * 4;
         return (hstart_off() + aux + 15) & ~(size_t)15;
     }
-    __host__ __device__ size_t scratch_off() const { return lhist_off() + KH_LHIST_BINS * 4; }
+    __host__ __device__ size_t tab_off() const { return lhist_off() + KH_LHIST_BINS * 4; }
+    __host__ __device__ size_t scratch_off() const { return tab_off() + 128 * 4; }
     __host__ __device__ size_t bcast_off() const { return scratch_off() + 32 * 4; }
     __host__ __device__ size_t total() const { return bcast_off() + 4 * 8; }
 };
@@ -375,12 +391,65 @@ size_t kh_sort_lds_bytes(int W, u32 cap, bool pay) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Block-wide decoupled look-back: all KH_SORT_THREADS threads inspect one predecessor each, so
+// the usual case costs one global round trip instead of a chain of 64-wide windows.
+// scratch: >= 24 u32 words (8-byte aligned at word 8).  Returns the exclusive prefix to every
+// thread.  Contains barriers: every thread of the block must call it.
+// ------------------------------------------------------------------------------------------
+__device__ u64 lookback_block(u64* desc, const u32 q, const u64 mine, u32* err, u32* scratch) {
+    const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6, nw = blockDim.x >> 6;
+    u32* first_in_wave = scratch;                               // [nw]
+    u64* wave_sum = reinterpret_cast<u64*>(scratch + 8);         // [nw]
+    if (q == 0) {
+        if (tid == 0) lb_store(&desc[0], KH_LB_PREFIX | mine);
+        return 0;
+    }
+    if (tid == 0) lb_store(&desc[q], KH_LB_AGG | mine);
+    u64 excl = 0;
+    long long base = (long long)q - 1;
+    bool timed_out = false;
+    while (true) {
+        const long long idx = base - (long long)tid;
+        u64 dsc = KH_LB_PREFIX;   // "before the first part": prefix 0
+        if (idx >= 0) {
+            dsc = lb_load(&desc[idx]);
+            u32 spins = 0;
+            while ((dsc >> 62) == 0) {
+                __builtin_amdgcn_s_sleep(2);
+                dsc = lb_load(&desc[idx]);
+                if (++spins > (1u << 22)) { timed_out = true; dsc = KH_LB_PREFIX; break; }
+            }
+        }
+        const u64 pm = __ballot((dsc >> 62) == 2);
+        if (lane == 0) first_in_wave[wid] = pm ? (u32)__ffsll((unsigned long long)pm) - 1u : 64u;
+        __syncthreads();
+        u32 tp = 0xffffffffu;   // nearest predecessor that already knows its inclusive prefix
+        for (u32 w = 0; w < nw; ++w) {
+            const u32 f = first_in_wave[w];
+            if (f < 64u) { tp = w * KH_WAVE + f; break; }
+        }
+        u64 v = (tid <= tp) ? (dsc & KH_LB_VALUE) : 0ull;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) wave_sum[wid] = v;
+        __syncthreads();
+        for (u32 w = 0; w < nw; ++w) excl += wave_sum[w];
+        if (tp != 0xffffffffu) break;
+        base -= (long long)blockDim.x;
+        __syncthreads();
+    }
+    if (__ballot(timed_out) && lane == 0) atomicOr(err, KH_ERR_SPIN_TIMEOUT);
+    if (tid == 0) lb_store(&desc[q], KH_LB_PREFIX | ((excl + mine) & KH_LB_VALUE));
+    return excl;
+}
+
+// ------------------------------------------------------------------------------------------
 // Distribution sort of one slot's keys, from registers into LDS.
 // Mixed keys are uniform inside a slot, so one counting pass over KH_FINE_BINS order-preserving
-// fine bins (about one key per bin) leaves the array sorted up to tiny per-bin permutations,
-// which one insertion pass per thread removes.  About 20x less LDS traffic than sorting the
-// slot with the bitonic network.  Equal keys land in one bin and cost O(run) to pass over;
-// only a bin crowded with DISTINCT keys would be slow, so a block whose fullest bin exceeds
+// fine bins (about one key per bin) leaves the array sorted up to tiny per-bin permutations.
+// Those are resolved by comparison counting: every key looks at the (few) keys of its own bin
+// and takes the rank "smaller keys + equal keys that arrived earlier".  Everything is
+// key-parallel; about 20x less LDS traffic than the bitonic network.  Equal keys share a bin
+// (cost: run^2 reads spread over the run's threads); a block whose fullest bin exceeds
 // KH_FINE_LIMIT falls back to the bitonic network (always correct).
 //   kreg/preg : this thread's keys (element e*NT + tid) and payloads
 //   bins      : LDS u32[KH_FINE_BINS + 1] (aliases hstart, which is only used afterwards)
@@ -394,7 +463,7 @@ __device__ __forceinline__ u32 fine_bin(const KmerKey<W>& key, int k, u32 nslots
 template <int W, bool PAY, int E>
 __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E], const u32 n,
                                 KmerKey<W>* s, u32* pay, u32* bins, u32* scratch, int k,
-                                u32 nslots) {
+                                u32 nslots, u32 q) {
     constexpr u32 NT = KH_SORT_THREADS;
     constexpr u32 PER = KH_FINE_BINS / NT;   // bins scanned per thread
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
@@ -410,6 +479,7 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
         }
     }
     __syncthreads();
+    KH_STAMP(q, 2);
     // exclusive scan of the bin counts (PER consecutive bins per thread) + fullest bin
     u32 c[PER], sum = 0, mx = 0;
 #pragma unroll
@@ -446,6 +516,7 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
     }
     if (tid == NT - 1) bins[KH_FINE_BINS] = run;
     __syncthreads();
+    KH_STAMP(q, 3);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if ((u32)e * NT + tid < n) {
@@ -455,39 +526,133 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
         }
     }
     __syncthreads();
+    KH_STAMP(q, 4);
     if (bmax > (u32)KH_FINE_LIMIT) {
         bitonic_sort_lds<W, PAY>(s, pay, n);
+        KH_STAMP(q, 5);
         return;
     }
-    // insertion pass over this thread's PER consecutive bins (elements never leave their bin)
-    const u32 lo = bins[tid * PER], hi = bins[tid * PER + PER];
-    for (u32 i = lo + 1; i < hi; ++i) {
-        const KmerKey<W> key = s[i];
-        u32 pv = 0;
-        if (PAY) pv = pay[i];
-        u32 j = i;
-        while (j > lo && key_lt(key, s[j - 1])) {
-            s[j] = s[j - 1];
-            if (PAY) pay[j] = pay[j - 1];
-            --j;
+    if (bmax > 1) {
+        // final position inside the bin by comparison counting (reads only; writes after the
+        // barrier).  fr[e] is reused for the final index.
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if ((u32)e * NT + tid < n) {
+                const u32 f = fr[e] >> 16, r = fr[e] & 0xffffu;
+                const u32 b0 = bins[f], cnt = bins[f + 1] - b0;
+                u32 pos = r;
+                if (cnt > 1) {
+                    pos = 0;
+                    for (u32 t = 0; t < cnt; ++t) {
+                        const KmerKey<W> o = s[b0 + t];
+                        pos += (key_lt(o, kreg[e]) || (t < r && key_eq(o, kreg[e]))) ? 1u : 0u;
+                    }
+                }
+                fr[e] = b0 + pos;
+            }
         }
-        if (j != i) {
-            s[j] = key;
-            if (PAY) pay[j] = pv;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if ((u32)e * NT + tid < n) {
+                s[fr[e]] = kreg[e];
+                if (PAY) pay[fr[e]] = preg[e];
+            }
         }
+        __syncthreads();
+    }
+    KH_STAMP(q, 5);
+}
+
+// ------------------------------------------------------------------------------------------
+// Run-length pass + ordered output over sorted s[0..n), n <= E * KH_SORT_THREADS.
+// Key-parallel throughout: (1) run heads by comparing neighbours, ranked with one table of
+// per-wave ballots (a single barrier), hstart[r] = start of run r; (2) eval(h0, h1) gives the
+// output counter of run r (0 = drop the key), kept runs are ranked the same way; (3) the slot's
+// kept count goes through the block-wide look-back; (4) consecutive lanes write consecutive
+// outputs (coalesced).  All threads of the block must call it.
+// ------------------------------------------------------------------------------------------
+template <int E>
+__device__ __forceinline__ void table_prefix(const u32* tab, const u32 wid, u32 (&base)[E], u32& total) {
+    u32 running = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        u32 before = 0, row = 0;
+#pragma unroll
+        for (u32 w = 0; w < KH_SORT_THREADS / KH_WAVE; ++w) {
+            const u32 v = tab[e * 8 + w];
+            before += (w < wid) ? v : 0u;
+            row += v;
+        }
+        base[e] = running + before;
+        running += row;
+    }
+    total = running;
+}
+
+template <int W, int E, class Eval, class Sink>
+__device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab, Eval eval, Sink sink,
+                         KhLookback lb, const u32 q, u32* scratch) {
+    constexpr u32 NT = KH_SORT_THREADS;
+    const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    u32 lr[E], base[E];
+    u32 flags = 0;
+    // ---- (1) run heads
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 i = (u32)e * NT + tid;
+        const bool head = (i < n) && (i == 0 || !key_eq(s[i], s[i - 1]));
+        const u64 bal = __ballot(head);
+        if (lane == 0) tab[e * 8 + wid] = (u32)__popcll(bal);
+        lr[e] = (u32)__popcll(bal & lt_mask);
+        flags |= head ? (1u << e) : 0u;
     }
     __syncthreads();
+    u32 d;
+    table_prefix<E>(tab, wid, base, d);
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (flags & (1u << e)) hstart[base[e] + lr[e]] = (u16)((u32)e * NT + tid);
+    if (tid == 0) hstart[d] = (u16)n;
+    __syncthreads();
+    KH_STAMP(q, 6);
+    // ---- (2) counters of the runs, kept runs ranked
+    u32 cnt[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 r = (u32)e * NT + tid;
+        cnt[e] = (r < d) ? eval((u32)hstart[r], (u32)hstart[r + 1]) : 0u;
+        const u64 bal = __ballot(cnt[e] != 0);
+        if (lane == 0) tab[e * 8 + wid] = (u32)__popcll(bal);
+        lr[e] = (u32)__popcll(bal & lt_mask);
+    }
+    __syncthreads();
+    u32 kept;
+    table_prefix<E>(tab, wid, base, kept);
+    // ---- (3) slot prefix
+    const u64 obase = lookback_block(lb.desc, q, (u64)kept, lb.err, scratch);
+    KH_STAMP(q, 7);
+    // ---- (4) output
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (cnt[e]) {
+            const u32 r = (u32)e * NT + tid;
+            sink(obase + base[e] + lr[e], s[hstart[r]], cnt[e]);
+        }
+    }
+    KH_STAMP(q, 8);
 }
 
 // ------------------------------------------------------------------------------------------
 // pass C: per-bucket sort + run-length count + ordered output
 // ------------------------------------------------------------------------------------------
-// Normal buckets (n <= cap): keys-only sort, counter = run length.
+// Normal buckets (n <= cap): keys-only distribution sort, counter = run length.
 // Oversize buckets (duplicate-heavy input, e.g. small k or low-complexity sequence): the
-// same LDS is re-carved as (key, counter) pairs of half the capacity and the bucket is
-// folded in chunks: [accumulated distinct pairs | next raw chunk] -> sort -> sum per key.
+// same LDS is re-carved as (key, counter) pairs and the bucket is folded in chunks:
+// [accumulated distinct pairs | next raw chunk] -> sort -> sum per key.
 // Only a bucket with more DISTINCT keys than the pair capacity cannot be handled; that
-// raises KH_ERR_CAPACITY (the host then re-runs the segment with more buckets).
+// raises KH_ERR_CAPACITY (the host then re-plans the batch with more buckets).
 template <int W>
 __global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
     const KmerKey<W>* __restrict__ part, const u64* __restrict__ bstart,
@@ -497,12 +662,12 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
     const SortLds L{lds_raw, cap, W, false};
     KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
     u16* hstart = reinterpret_cast<u16*>(lds_raw + L.hstart_off());
+    u32* tab = reinterpret_cast<u32*>(lds_raw + L.tab_off());
     u32* scratch = reinterpret_cast<u32*>(lds_raw + L.scratch_off());
-    u64* bcast = reinterpret_cast<u64*>(lds_raw + L.bcast_off());
-    // pair-mode carve (oversize path): keys[capp] | pay[capp] inside the key region;
-    // hstart is reused as is (capp < cap).
+    // pair-mode carve (oversize path): keys[capp] | pay[capp] inside the key region
     const u32 capp = ((cap * 8u * W) / (8u * W + 4u)) & ~63u;
     u32* pay = reinterpret_cast<u32*>(lds_raw + (size_t)capp * 8 * W);
+    constexpr int E = (W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2) / KH_SORT_THREADS;
 
     const u32 tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) {
@@ -521,15 +686,15 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
     const u32 seg_nb = scratch[17];
     const u64 lo = bstart[q], hi = bstart[q + 1];
     const u64 n64 = hi - lo;
-    const bool filt = (ci > 1u) || (cx != 0xffffffffu);
+    KH_STAMP(q, 0);
 
-    u32 d = 0;            // distinct keys now in LDS
-    bool pairs = false;   // counters live in pay[] (else: run lengths via hstart)
-    bool fail = false;
+    auto sink = [&](u64 o, const KmerKey<W>& key, u32 c) {
+        out_keys[o] = key;
+        if (out_counts) out_counts[o] = c < cs ? c : cs;
+    };
 
     if (n64 <= cap) {
         const u32 n = (u32)n64;
-        constexpr int E = (W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2) / KH_SORT_THREADS;
         KmerKey<W> kreg[E];
         u32 preg[E];
 #pragma unroll
@@ -539,95 +704,64 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
             const u32 i = (u32)e * KH_SORT_THREADS + tid;
             if (i < n) kreg[e] = part[lo + i];
         }
+#ifdef KH_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        KH_STAMP(q, 1);
         distribute_sort<W, false, E>(kreg, preg, n, s, nullptr, reinterpret_cast<u32*>(hstart),
-                                     scratch, k, seg_nb);
-        d = find_runs<W>(s, n, hstart, scratch);
-    } else {
-        pairs = true;
-        u32 acc = 0;
-        u64 consumed = 0;
-        while (consumed < n64) {
-            if (acc >= capp) { fail = true; break; }
-            const u64 left = n64 - consumed;
-            const u32 take = left < (u64)(capp - acc) ? (u32)left : (capp - acc);
-            const u32 m = acc + take;
-            for (u32 i = acc + tid; i < m; i += nt) {
-                s[i] = part[lo + consumed + (i - acc)];
-                pay[i] = 1u;
+                                     scratch, k, seg_nb, q);
+        auto eval = [&](u32 h0, u32 h1) -> u32 {
+            const u32 c = h1 - h0;
+            return (c >= ci && c <= cx) ? c : 0u;
+        };
+        rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch);
+        return;
+    }
+
+    // ---- oversize bucket: fold chunk by chunk into (key, counter) pairs
+    u32 acc = 0;
+    u64 consumed = 0;
+    bool fail = false;
+    while (consumed < n64) {
+        if (acc >= capp) { fail = true; break; }
+        const u64 left = n64 - consumed;
+        const u32 take = left < (u64)(capp - acc) ? (u32)left : (capp - acc);
+        const u32 m = acc + take;
+        for (u32 i = acc + tid; i < m; i += nt) {
+            s[i] = part[lo + consumed + (i - acc)];
+            pay[i] = 1u;
+        }
+        __syncthreads();
+        bitonic_sort_lds<W, true>(s, pay, m);
+        const u32 dd = find_runs<W>(s, m, hstart, scratch);
+        // fold runs in place: slot r <- (key, saturating sum of payloads)
+        for (u32 r0 = 0; r0 < dd; r0 += nt) {
+            const u32 r = r0 + tid;
+            KmerKey<W> kv = key_zero<W>();
+            u64 sum = 0;
+            if (r < dd) {
+                const u32 h0 = hstart[r], h1 = hstart[r + 1];
+                kv = s[h0];
+                for (u32 j = h0; j < h1; ++j) sum += pay[j];
+                if (sum > 0xffffffffull) sum = 0xffffffffull;
             }
             __syncthreads();
-            bitonic_sort_lds<W, true>(s, pay, m);
-            const u32 dd = find_runs<W>(s, m, hstart, scratch);
-            // fold runs in place: slot r <- (key, saturating sum of payloads)
-            for (u32 r0 = 0; r0 < dd; r0 += nt) {
-                const u32 r = r0 + tid;
-                KmerKey<W> kv = key_zero<W>();
-                u64 sum = 0;
-                if (r < dd) {
-                    const u32 h0 = hstart[r], h1 = hstart[r + 1];
-                    kv = s[h0];
-                    for (u32 j = h0; j < h1; ++j) sum += pay[j];
-                    if (sum > 0xffffffffull) sum = 0xffffffffull;
-                }
-                __syncthreads();
-                if (r < dd) { s[r] = kv; pay[r] = (u32)sum; }
-                __syncthreads();
-            }
-            acc = dd;
-            consumed += take;
+            if (r < dd) { s[r] = kv; pay[r] = (u32)sum; }
+            __syncthreads();
         }
-        d = acc;
+        acc = dd;
+        consumed += take;
     }
     if (fail) {
         if (tid == 0) atomicOr(lb.err, KH_ERR_CAPACITY);
-        d = 0;
+        acc = 0;
     }
-
-    // counter of output r and whether it survives -ci/-cx
-    auto counter = [&](u32 r) -> u32 {
-        return pairs ? pay[r] : (u32)(hstart[r + 1] - hstart[r]);
+    // s[0..acc) now holds distinct keys with their counters in pay[] (acc <= capp < cap)
+    auto eval = [&](u32 h0, u32 h1) -> u32 {
+        const u32 c = pay[h0];
+        return (c >= ci && c <= cx) ? c : 0u;
     };
-    u32 dk = d;
-    if (filt) {
-        u32 mine = 0;
-        for (u32 r = tid; r < d; r += nt) {
-            const u32 c = counter(r);
-            mine += (c >= ci && c <= cx) ? 1u : 0u;
-        }
-        // block sum through ballot-free LDS reduction
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-        if (lane_id() == 0) scratch[tid >> 6] = mine;
-        __syncthreads();
-        dk = 0;
-        for (u32 w = 0; w < (nt >> 6); ++w) dk += scratch[w];
-        __syncthreads();
-    }
-
-    if (tid < KH_WAVE) {
-        const u64 excl = lookback_wave(lb.desc, q, (u64)dk, lb.err);
-        if (tid == 0) bcast[0] = excl;
-    }
-    __syncthreads();
-    const u64 obase = bcast[0];
-
-    u32 running = 0;
-    for (u32 r0 = 0; r0 < d; r0 += nt) {
-        const u32 r = r0 + tid;
-        u32 c = 0;
-        bool keep = false;
-        if (r < d) {
-            c = counter(r);
-            keep = !filt || (c >= ci && c <= cx);
-        }
-        u32 tot;
-        const u32 rk = block_rank(keep, scratch, tot);
-        if (keep) {
-            const u64 o = obase + running + rk;
-            out_keys[o] = pairs ? s[r] : s[hstart[r]];
-            if (out_counts) out_counts[o] = c < cs ? c : cs;
-        }
-        running += tot;
-    }
+    rle_emit<W, E>(s, acc, hstart, tab, eval, sink, lb, q, scratch);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -679,30 +813,42 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
     u32* pay = reinterpret_cast<u32*>(lds_raw + L.pay_off());
     u16* hstart = reinterpret_cast<u16*>(lds_raw + L.hstart_off());
     u32* lhist = reinterpret_cast<u32*>(lds_raw + L.lhist_off());
+    u32* tab = reinterpret_cast<u32*>(lds_raw + L.tab_off());
     u32* scratch = reinterpret_cast<u32*>(lds_raw + L.scratch_off());
     u64* bcast = reinterpret_cast<u64*>(lds_raw + L.bcast_off());
-    // while gathering, lhist holds the operand slices: soff[g] = first LDS index of slice g
-    // (words 0..63) and sbeg[g] = first element of the slice inside operand g (words 64..191)
     constexpr int CAPC = PAY ? (W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2)
                              : (W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2);
     constexpr int E = (CAPC + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
-    u32* soff = lhist;
-    u64* sbeg = reinterpret_cast<u64*>(lhist + 64);
-    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const u32 tid = threadIdx.x, nt = blockDim.x, lane = lane_id();
     if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
     __syncthreads();
     const u32 q = scratch[16];
     const u64 per = (u64)nranges + 1;
+    KH_STAMP(q, 0);
 
-    if (tid == 0) {
-        u64 tot = 0;
-        for (u32 g = 0; g < nsets; ++g) {
-            const u64 b0 = bounds[g * per + q], b1 = bounds[g * per + q + 1];
-            soff[g] = (u32)(tot > 0xffffffffull ? 0xffffffffull : tot);
-            sbeg[g] = b0;
-            tot += b1 - b0;
+    // operand slices of this slot, described in LDS while gathering (lhist is free until then):
+    //   soff[g] u32 (words 0..63)   first gathered index of operand g's slice (exclusive scan)
+    //   sbeg[g] u64 (words 64..191) first element of the slice inside operand g
+    u32* soff = lhist;
+    u64* sbeg = reinterpret_cast<u64*>(lhist + 64);
+    if (tid < KH_WAVE) {   // nsets <= 64: one wave scans the slice lengths
+        u64 len = 0;
+        if (tid < nsets) {
+            const u64 b0 = bounds[tid * per + q], b1 = bounds[tid * per + q + 1];
+            sbeg[tid] = b0;
+            len = b1 - b0;
         }
-        bcast[1] = tot;
+        u64 incl = len;
+#pragma unroll
+        for (int off = 1; off < KH_WAVE; off <<= 1) {
+            const u64 u = __shfl_up(incl, off);
+            if (lane >= (u32)off) incl += u;
+        }
+        if (tid < nsets) {
+            const u64 ex = incl - len;
+            soff[tid] = ex > 0xffffffffull ? 0xffffffffu : (u32)ex;
+        }
+        if (tid == KH_WAVE - 1) bcast[1] = incl;
     }
     __syncthreads();
     const u64 n64 = bcast[1];
@@ -712,6 +858,8 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
     } else {
         n = (u32)n64;
     }
+    // gather straight into registers: element i of the concatenated slices belongs to the last
+    // operand whose slice starts at or before i; all loads of a thread are independent
     KmerKey<W> kreg[E];
     u32 preg[E];
 #pragma unroll
@@ -720,7 +868,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
         preg[e] = 0;
         const u32 i = (u32)e * KH_SORT_THREADS + tid;
         if (i < n) {
-            u32 ga = 0, gb = nsets;          // last operand whose slice starts at or before i
+            u32 ga = 0, gb = nsets;
             while (gb - ga > 1) {
                 const u32 m = (ga + gb) >> 1;
                 if (soff[m] <= i) ga = m; else gb = m;
@@ -736,23 +884,25 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
             }
         }
     }
-    __syncthreads();
+    __syncthreads();   // soff / sbeg no longer needed
     for (u32 i = tid; i < KH_LHIST_BINS; i += nt) lhist[i] = 0;
+#ifdef KH_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    KH_STAMP(q, 1);
     distribute_sort<W, PAY, E>(kreg, preg, n, s, pay, reinterpret_cast<u32*>(hstart), scratch, k,
-                               nranges);
-    const u32 d = n ? find_runs<W>(s, n, hstart, scratch) : 0u;
+                               nranges, q);
 
-    // evaluate run r: returns counter (0 = dropped)
-    auto eval = [&](u32 r) -> u32 {
-        const u32 h0 = hstart[r], h1 = hstart[r + 1];
+    // counter of run s[h0..h1) under the requested operation (0 = key dropped)
+    auto eval = [&](u32 h0, u32 h1) -> u32 {
         long long c;
         if (!PAY) {
             c = (long long)(h1 - h0);
         } else {
             long long ca = 0, cb = 0;
             bool ha = false, hb = false;
-            for (u32 j = h0; j < h1; ++j) {
-                const u32 p = pay[j];
+            for (u32 t = h0; t < h1; ++t) {
+                const u32 p = pay[t];
                 if (p >> 31) { cb += p & 0x7fffffffu; hb = true; } else { ca += p; ha = true; }
             }
             switch (op) {
@@ -773,42 +923,15 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
         if (c <= 0) return 0u;
         return c > (long long)cs ? cs : (u32)c;
     };
-
-    // pass 1: how many keys survive (needed before the look-back)
-    u32 mine = 0;
-    for (u32 r = tid; r < d; r += nt) mine += eval(r) ? 1u : 0u;
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-    if (lane_id() == 0) scratch[tid >> 6] = mine;
-    __syncthreads();
-    u32 dk = 0;
-    for (u32 w = 0; w < (nt >> 6); ++w) dk += scratch[w];
-    __syncthreads();
-
-    if (tid < KH_WAVE) {
-        const u64 excl = lookback_wave(lb.desc, q, (u64)dk, lb.err);
-        if (tid == 0) bcast[0] = excl;
-    }
-    __syncthreads();
-    const u64 obase = bcast[0];
-
-    u32 running = 0;
-    for (u32 r0 = 0; r0 < d; r0 += nt) {
-        const u32 r = r0 + tid;
-        const u32 c = (r < d) ? eval(r) : 0u;
-        const bool keep = c != 0;
-        u32 tot;
-        const u32 rk = block_rank(keep, scratch, tot);
-        if (keep) {
-            const u64 o = obase + running + rk;
-            out_keys[o] = s[hstart[r]];
-            if (out_counts) out_counts[o] = c;
-            if (hist) {
-                if (c < KH_LHIST_BINS) atomicAdd(&lhist[c], 1u);
-                else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
-            }
+    auto sink = [&](u64 o, const KmerKey<W>& key, u32 c) {
+        out_keys[o] = key;
+        if (out_counts) out_counts[o] = c;
+        if (hist) {
+            if (c < KH_LHIST_BINS) atomicAdd(&lhist[c], 1u);
+            else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
         }
-        running += tot;
-    }
+    };
+    rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch);
     if (hist) {
         __syncthreads();
         for (u32 i = tid; i < KH_LHIST_BINS; i += nt) {
