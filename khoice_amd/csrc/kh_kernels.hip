@@ -365,7 +365,8 @@ __device__ u32 find_runs(const KmerKey<W>* s, u32 n, u16* hstart, u32* wave_tot)
 
 // LDS carve shared by k_bucket_sort_rle and k_setop (everything lives in dynamic LDS so that
 // its base stays 16-B aligned):  keys[cap] | pay[cap] (optional) | aux | lhist[KH_LHIST_BINS] |
-// tab[128] | scratch[32] u32 | bcast[4] u64, where aux holds the fine-bin table
+// tab[128 + KH_FINE_BINS/32 + KH_WORKLIST] (ballot table, dirty-bin bitmap, repair work list) |
+// scratch[32] u32 | bcast[4] u64, where aux holds the fine-bin table
 // bins[KH_FINE_BINS+1] u32 while sorting and hstart[cap+2] u16 afterwards.
 struct SortLds {
     u8* base;
@@ -377,11 +378,13 @@ struct SortLds {
     __host__ __device__ size_t hstart_off() const { return pay_off() + (pay ? (size_t)cap * 4 : 0); }
     __host__ __device__ size_t lhist_off() const {
         size_t aux = ((size_t)cap + 2) * 2;
-        if (aux < (size_t)(KH_FINE_BINS + 1) * 4) aux = (size_t)(KH_FINE_BINS + 1) * 4;
+        if (aux < (size_t)(KH_FINE_BINS / 2 + 1) * 4) aux = (size_t)(KH_FINE_BINS / 2 + 1) * 4;
         return (hstart_off() + aux + 15) & ~(size_t)15;
     }
     __host__ __device__ size_t tab_off() const { return lhist_off() + KH_LHIST_BINS * 4; }
-    __host__ __device__ size_t scratch_off() const { return tab_off() + 128 * 4; }
+    __host__ __device__ size_t scratch_off() const {
+        return tab_off() + (128 + KH_FINE_BINS / 32 + KH_WORKLIST) * 4;
+    }
     __host__ __device__ size_t bcast_off() const { return scratch_off() + 32 * 4; }
     __host__ __device__ size_t total() const { return bcast_off() + 4 * 8; }
 };
@@ -445,48 +448,61 @@ __device__ u64 lookback_block(u64* desc, const u32 q, const u64 mine, u32* err, 
 // ------------------------------------------------------------------------------------------
 // Distribution sort of one slot's keys, from registers into LDS.
 // Mixed keys are uniform inside a slot, so one counting pass over KH_FINE_BINS order-preserving
-// fine bins (about one key per bin) leaves the array sorted up to tiny per-bin permutations.
-// Those are resolved by comparison counting: every key looks at the (few) keys of its own bin
-// and takes the rank "smaller keys + equal keys that arrived earlier".  Everything is
-// key-parallel; about 20x less LDS traffic than the bitonic network.  Equal keys share a bin
-// (cost: run^2 reads spread over the run's threads); a block whose fullest bin exceeds
-// KH_FINE_LIMIT falls back to the bitonic network (always correct).
+// fine bins (about 0.4 keys per bin) leaves the array sorted up to tiny per-bin permutations.
+// The first key to arrive in a bin is its leader; a leader whose bin holds more than one key
+// tidies the bin with a serial insertion pass, which is linear when the bin holds copies of
+// one key (set unions, repeats) and touches 2-3 keys otherwise.  Everything else is
+// key-parallel; about 20x less LDS traffic than the bitonic network, to which a block whose
+// fullest bin exceeds KH_FINE_LIMIT falls back (always correct).
 //   kreg/preg : this thread's keys (element e*NT + tid) and payloads
-//   bins      : LDS u32[KH_FINE_BINS + 1] (aliases hstart, which is only used afterwards)
+//   bins      : LDS u32[KH_FINE_BINS / 2 + 1], two 16-bit bins per word (counts, then bases);
+//               aliases hstart, which is only used afterwards
+//   dirty     : LDS bitmap u32[KH_FINE_BINS / 32] of bins that arrived out of order
+//   wl        : LDS u32[KH_WORKLIST] work list of the keys of those bins
 // ------------------------------------------------------------------------------------------
 template <int W>
 __device__ __forceinline__ u32 fine_bin(const KmerKey<W>& key, int k, u32 nslots) {
     const u32 frac = (u32)((u64)kh_top32(key, k) * (u64)nslots);   // position inside the slot
     return frac >> (32 - KH_FINE_BITS);
 }
+__device__ __forceinline__ u32 bin_base(const u32* bins, u32 f) {
+    return (bins[f >> 1] >> (16 * (f & 1))) & 0xffffu;
+}
 
 template <int W, bool PAY, int E>
 __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E], const u32 n,
-                                KmerKey<W>* s, u32* pay, u32* bins, u32* scratch, int k,
-                                u32 nslots, u32 q) {
+                                KmerKey<W>* s, u32* pay, u32* bins, u32* dirty, u32* wl,
+                                u32* scratch, int k, u32 nslots, u32 q) {
     constexpr u32 NT = KH_SORT_THREADS;
-    constexpr u32 PER = KH_FINE_BINS / NT;   // bins scanned per thread
+    constexpr u32 WORDS = KH_FINE_BINS / 2;
+    constexpr u32 PER = WORDS / NT;   // packed words scanned per thread
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    for (u32 i = tid; i <= (u32)KH_FINE_BINS; i += NT) bins[i] = 0;
+    for (u32 i = tid; i <= WORDS; i += NT) bins[i] = 0;
+    for (u32 i = tid; i < (u32)KH_FINE_BINS / 32; i += NT) dirty[i] = 0;
+    if (tid == 0) scratch[20] = 0;   // work-list length
     __syncthreads();
-    u32 fr[E];
+    u32 fr[E];   // fine bin << 16 | arrival rank inside the bin
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         fr[e] = 0;
         if ((u32)e * NT + tid < n) {
             const u32 f = fine_bin<W>(kreg[e], k, nslots);
-            fr[e] = (f << 16) | atomicAdd(&bins[f], 1u);
+            const u32 sh = 16 * (f & 1);
+            const u32 old = atomicAdd(&bins[f >> 1], 1u << sh);
+            fr[e] = (f << 16) | ((old >> sh) & 0xffffu);
         }
     }
     __syncthreads();
     KH_STAMP(q, 2);
-    // exclusive scan of the bin counts (PER consecutive bins per thread) + fullest bin
+    // exclusive scan of the bin counts (PER consecutive words per thread) + fullest bin
     u32 c[PER], sum = 0, mx = 0;
 #pragma unroll
     for (u32 j = 0; j < PER; ++j) {
         c[j] = bins[tid * PER + j];
-        mx = c[j] > mx ? c[j] : mx;
-        sum += c[j];
+        const u32 c0 = c[j] & 0xffffu, c1 = c[j] >> 16;
+        mx = c0 > mx ? c0 : mx;
+        mx = c1 > mx ? c1 : mx;
+        sum += c0 + c1;
     }
     u32 incl = sum;
 #pragma unroll
@@ -511,16 +527,17 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
     u32 run = wbase + incl - sum;
 #pragma unroll
     for (u32 j = 0; j < PER; ++j) {
-        bins[tid * PER + j] = run;
-        run += c[j];
+        const u32 c0 = c[j] & 0xffffu, c1 = c[j] >> 16;
+        bins[tid * PER + j] = run | ((run + c0) << 16);
+        run += c0 + c1;
     }
-    if (tid == NT - 1) bins[KH_FINE_BINS] = run;
+    if (tid == NT - 1) bins[WORDS] = run;   // base of the bin past the last one = n
     __syncthreads();
     KH_STAMP(q, 3);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if ((u32)e * NT + tid < n) {
-            const u32 at = bins[fr[e] >> 16] + (fr[e] & 0xffffu);
+            const u32 at = bin_base(bins, fr[e] >> 16) + (fr[e] & 0xffffu);
             s[at] = kreg[e];
             if (PAY) pay[at] = preg[e];
         }
@@ -533,30 +550,66 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
         return;
     }
     if (bmax > 1) {
-        // final position inside the bin by comparison counting (reads only; writes after the
-        // barrier).  fr[e] is reused for the final index.
+        // (a) a bin is out of order iff some key is smaller than its predecessor in the bin
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if ((u32)e * NT + tid < n && (fr[e] & 0xffffu) != 0) {
+                const u32 f = fr[e] >> 16;
+                const u32 at = bin_base(bins, f) + (fr[e] & 0xffffu);
+                if (key_lt(kreg[e], s[at - 1])) atomicOr(&dirty[f >> 5], 1u << (f & 31));
+            }
+        }
+        __syncthreads();
+        // (b) keys of out-of-order bins (a few per cent of all keys) enter a work list, so that
+        // the repair below runs with dense lanes instead of diverging over all keys
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             if ((u32)e * NT + tid < n) {
-                const u32 f = fr[e] >> 16, r = fr[e] & 0xffffu;
-                const u32 b0 = bins[f], cnt = bins[f + 1] - b0;
-                u32 pos = r;
-                if (cnt > 1) {
-                    pos = 0;
-                    for (u32 t = 0; t < cnt; ++t) {
-                        const KmerKey<W> o = s[b0 + t];
-                        pos += (key_lt(o, kreg[e]) || (t < r && key_eq(o, kreg[e]))) ? 1u : 0u;
-                    }
+                const u32 f = fr[e] >> 16;
+                if ((dirty[f >> 5] >> (f & 31)) & 1u) {
+                    const u32 at = bin_base(bins, f) + (fr[e] & 0xffffu);
+                    const u32 w = atomicAdd(&scratch[20], 1u);
+                    if (w < (u32)KH_WORKLIST) wl[w] = at | (f << 12);
                 }
-                fr[e] = b0 + pos;
+            }
+        }
+        __syncthreads();
+        const u32 wlc = scratch[20];
+        if (wlc > (u32)KH_WORKLIST) {   // too disordered for the list: sort everything
+            bitonic_sort_lds<W, PAY>(s, pay, n);
+            KH_STAMP(q, 5);
+            return;
+        }
+        // (c) final place of a listed key: smaller keys of its bin + equal keys before it
+        constexpr int IT = KH_WORKLIST / NT;
+        KmerKey<W> wk[IT];
+        u32 wp[IT], wdst[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            wdst[it] = 0xffffffffu;
+            wp[it] = 0;
+            wk[it] = key_zero<W>();
+            const u32 w = (u32)it * NT + tid;
+            if (w < wlc) {
+                const u32 item = wl[w];
+                const u32 at = item & 0xfffu, f = item >> 12;
+                const u32 b0 = bin_base(bins, f), cnt = bin_base(bins, f + 1) - b0, r = at - b0;
+                wk[it] = s[at];
+                if (PAY) wp[it] = pay[at];
+                u32 pos = 0;
+                for (u32 t = 0; t < cnt; ++t) {
+                    const KmerKey<W> o = s[b0 + t];
+                    pos += (key_lt(o, wk[it]) || (t < r && key_eq(o, wk[it]))) ? 1u : 0u;
+                }
+                wdst[it] = b0 + pos;
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if ((u32)e * NT + tid < n) {
-                s[fr[e]] = kreg[e];
-                if (PAY) pay[fr[e]] = preg[e];
+        for (int it = 0; it < IT; ++it) {
+            if (wdst[it] != 0xffffffffu) {
+                s[wdst[it]] = wk[it];
+                if (PAY) pay[wdst[it]] = wp[it];
             }
         }
         __syncthreads();
@@ -572,31 +625,35 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
 // kept count goes through the block-wide look-back; (4) consecutive lanes write consecutive
 // outputs (coalesced).  All threads of the block must call it.
 // ------------------------------------------------------------------------------------------
+// tab[e * 8 + w] holds the number of flagged lanes of wave w in pass e (E * 8 <= 64 entries).
+// One wave turns the table into its exclusive prefix (pass-major order) and stores the grand
+// total behind it; two barriers inside.
 template <int E>
-__device__ __forceinline__ void table_prefix(const u32* tab, const u32 wid, u32 (&base)[E], u32& total) {
-    u32 running = 0;
+__device__ __forceinline__ void table_scan(u32* tab) {
+    static_assert(E * 8 <= KH_WAVE, "one wave scans the ballot table");
+    __syncthreads();
+    if (threadIdx.x < KH_WAVE) {
+        const u32 lane = threadIdx.x;
+        const u32 v = lane < (u32)E * 8 ? tab[lane] : 0u;
+        u32 incl = v;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        u32 before = 0, row = 0;
-#pragma unroll
-        for (u32 w = 0; w < KH_SORT_THREADS / KH_WAVE; ++w) {
-            const u32 v = tab[e * 8 + w];
-            before += (w < wid) ? v : 0u;
-            row += v;
+        for (int off = 1; off < KH_WAVE; off <<= 1) {
+            const u32 u = __shfl_up(incl, off);
+            if (lane >= (u32)off) incl += u;
         }
-        base[e] = running + before;
-        running += row;
+        if (lane < (u32)E * 8) tab[lane] = incl - v;
+        if (lane == KH_WAVE - 1) tab[E * 8] = incl;
     }
-    total = running;
+    __syncthreads();
 }
 
 template <int W, int E, class Eval, class Sink>
 __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab, Eval eval, Sink sink,
-                         KhLookback lb, const u32 q, u32* scratch) {
+                         KhLookback lb, const u32 q, u32* scratch, const bool all_kept) {
     constexpr u32 NT = KH_SORT_THREADS;
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const u64 lt_mask = (1ull << lane) - 1ull;
-    u32 lr[E], base[E];
+    u32 lr[E];
     u32 flags = 0;
     // ---- (1) run heads
 #pragma unroll
@@ -608,12 +665,14 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
         lr[e] = (u32)__popcll(bal & lt_mask);
         flags |= head ? (1u << e) : 0u;
     }
-    __syncthreads();
-    u32 d;
-    table_prefix<E>(tab, wid, base, d);
+    table_scan<E>(tab);
+    const u32 d = tab[E * 8];
+    // when no run can be dropped the slot's output count is already known: publish it now so
+    // that it is visible to the successors by the time they look back
+    if (all_kept && q != 0 && tid == 0) lb_store(&lb.desc[q], KH_LB_AGG | (u64)d);
 #pragma unroll
     for (int e = 0; e < E; ++e)
-        if (flags & (1u << e)) hstart[base[e] + lr[e]] = (u16)((u32)e * NT + tid);
+        if (flags & (1u << e)) hstart[tab[e * 8 + wid] + lr[e]] = (u16)((u32)e * NT + tid);
     if (tid == 0) hstart[d] = (u16)n;
     __syncthreads();
     KH_STAMP(q, 6);
@@ -627,9 +686,10 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
         if (lane == 0) tab[e * 8 + wid] = (u32)__popcll(bal);
         lr[e] = (u32)__popcll(bal & lt_mask);
     }
-    __syncthreads();
-    u32 kept;
-    table_prefix<E>(tab, wid, base, kept);
+    table_scan<E>(tab);
+    const u32 kept = tab[E * 8];
+#pragma unroll
+    for (int e = 0; e < E; ++e) lr[e] += tab[e * 8 + wid];
     // ---- (3) slot prefix
     const u64 obase = lookback_block(lb.desc, q, (u64)kept, lb.err, scratch);
     KH_STAMP(q, 7);
@@ -638,7 +698,7 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
     for (int e = 0; e < E; ++e) {
         if (cnt[e]) {
             const u32 r = (u32)e * NT + tid;
-            sink(obase + base[e] + lr[e], s[hstart[r]], cnt[e]);
+            sink(obase + lr[e], s[hstart[r]], cnt[e]);
         }
     }
     KH_STAMP(q, 8);
@@ -709,12 +769,12 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
 #endif
         KH_STAMP(q, 1);
         distribute_sort<W, false, E>(kreg, preg, n, s, nullptr, reinterpret_cast<u32*>(hstart),
-                                     scratch, k, seg_nb, q);
+                                     tab + 128, tab + 128 + KH_FINE_BINS / 32, scratch, k, seg_nb, q);
         auto eval = [&](u32 h0, u32 h1) -> u32 {
             const u32 c = h1 - h0;
             return (c >= ci && c <= cx) ? c : 0u;
         };
-        rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch);
+        rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch, ci <= 1u && cx == 0xffffffffu);
         return;
     }
 
@@ -761,7 +821,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
         const u32 c = pay[h0];
         return (c >= ci && c <= cx) ? c : 0u;
     };
-    rle_emit<W, E>(s, acc, hstart, tab, eval, sink, lb, q, scratch);
+    rle_emit<W, E>(s, acc, hstart, tab, eval, sink, lb, q, scratch, ci <= 1u && cx == 0xffffffffu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -827,15 +887,25 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
     KH_STAMP(q, 0);
 
     // operand slices of this slot, described in LDS while gathering (lhist is free until then):
-    //   soff[g] u32 (words 0..63)   first gathered index of operand g's slice (exclusive scan)
-    //   sbeg[g] u64 (words 64..191) first element of the slice inside operand g
+    //   soff[g] u32  (words   0.. 63) first gathered index of operand g's slice (exclusive scan)
+    //   suni[g] u32  (words  64..127) uniform counter of operand g
+    //   sbeg[g] u64  (words 128..255) first element of the slice inside operand g
+    //   skey[g] u64  (words 256..383) operand g's key array
+    //   scnt[g] u64  (words 384..511) operand g's counter array (0 = uniform)
     u32* soff = lhist;
-    u64* sbeg = reinterpret_cast<u64*>(lhist + 64);
+    u32* suni = lhist + 64;
+    u64* sbeg = reinterpret_cast<u64*>(lhist + 128);
+    u64* skey = reinterpret_cast<u64*>(lhist + 256);
+    u64* scnt = reinterpret_cast<u64*>(lhist + 384);
     if (tid < KH_WAVE) {   // nsets <= 64: one wave scans the slice lengths
         u64 len = 0;
         if (tid < nsets) {
             const u64 b0 = bounds[tid * per + q], b1 = bounds[tid * per + q + 1];
+            const KhSetView sv = sets[tid];
             sbeg[tid] = b0;
+            skey[tid] = reinterpret_cast<u64>(sv.keys);
+            scnt[tid] = reinterpret_cast<u64>(sv.counts);
+            suni[tid] = sv.uniform;
             len = b1 - b0;
         }
         u64 incl = len;
@@ -873,25 +943,25 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
                 const u32 m = (ga + gb) >> 1;
                 if (soff[m] <= i) ga = m; else gb = m;
             }
-            const KhSetView sv = sets[ga];
             const u64 idx = sbeg[ga] + (i - soff[ga]);
-            kreg[e] = reinterpret_cast<const KmerKey<W>*>(sv.keys)[idx];
+            kreg[e] = reinterpret_cast<const KmerKey<W>*>(skey[ga])[idx];
             if (PAY) {
-                u32 c = sv.counts ? sv.counts[idx] : sv.uniform;
+                const u32* cp = reinterpret_cast<const u32*>(scnt[ga]);
+                u32 c = cp ? cp[idx] : suni[ga];
                 if (c > 0x7fffffffu) c = 0x7fffffffu;
                 // binary operations tag the second operand; n-ary unions only ever sum
                 preg[e] = c | ((nsets == 2 && ga == 1) ? 0x80000000u : 0u);
             }
         }
     }
-    __syncthreads();   // soff / sbeg no longer needed
+    __syncthreads();   // the slice descriptors are no longer needed
     for (u32 i = tid; i < KH_LHIST_BINS; i += nt) lhist[i] = 0;
 #ifdef KH_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     KH_STAMP(q, 1);
-    distribute_sort<W, PAY, E>(kreg, preg, n, s, pay, reinterpret_cast<u32*>(hstart), scratch, k,
-                               nranges, q);
+    distribute_sort<W, PAY, E>(kreg, preg, n, s, pay, reinterpret_cast<u32*>(hstart), tab + 128,
+                               tab + 128 + KH_FINE_BINS / 32, scratch, k, nranges, q);
 
     // counter of run s[h0..h1) under the requested operation (0 = key dropped)
     auto eval = [&](u32 h0, u32 h1) -> u32 {
@@ -931,7 +1001,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
             else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
         }
     };
-    rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch);
+    rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch, op == KH_OP_UNION && mode != KH_OC_DIFF);
     if (hist) {
         __syncthreads();
         for (u32 i = tid; i < KH_LHIST_BINS; i += nt) {
