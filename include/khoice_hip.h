@@ -124,6 +124,9 @@ int kh_dump_sorted(kh_ctx *ctx, const kh_set *set, const char *path);
 void kh_set_free(kh_set *set);
 int kh_set_info(const kh_set *set, uint64_t *n, int *k, int *words_per_key, int *has_counts,
                 uint32_t *uniform_count);
+/* saturation value the set's counters were produced with (kmc -cs, OUTPUT_PARAMS -cs, or the
+ * kmc_tools default 255); `kmc_tools transform histogram` prints 2^(8*bytes(counter_max))-1 lines */
+int kh_set_counter_max(const kh_set *set, uint32_t *counter_max);
 /* copy to host in storage order (NOT sorted by key): keys un-mixed, n*W words; counts n */
 int kh_set_download(kh_ctx *ctx, const kh_set *set, uint64_t *keys, uint32_t *counts);
 /* build a set from host arrays of DISTINCT keys in any order (counts may be NULL => 1) */

@@ -259,7 +259,8 @@ extern "C" int kh_set_info(const kh_set* s, uint64_t* n, int* k, int* w, int* ha
     if (uniform) *uniform = s->uniform;
     return KH_OK;
 }
-static kh_set* make_set(int k, u64 n, DevBuf* kb, size_t koff, DevBuf* cb, size_t coff, u32 uniform) {
+static kh_set* make_set(int k, u64 n, DevBuf* kb, size_t koff, DevBuf* cb, size_t coff, u32 uniform,
+                        u32 counter_max = KH_KMC_DEFAULT_CS) {
     kh_set* s = new kh_set;
     s->k = k;
     s->W = k <= 32 ? 1 : 2;
@@ -269,10 +270,17 @@ static kh_set* make_set(int k, u64 n, DevBuf* kb, size_t koff, DevBuf* cb, size_
     s->cb = cb;
     s->coff = coff;
     s->uniform = uniform;
+    s->counter_max = counter_max;
     return s;
 }
 static int check_k(int k) {
     if (k < 1 || k > 64) return kh_fail(KH_E_ARG, "k=%d outside the supported range 1..64", k);
+    return KH_OK;
+}
+
+extern "C" int kh_set_counter_max(const kh_set* s, uint32_t* counter_max) {
+    if (!s || !counter_max) return kh_fail(KH_E_ARG, "kh_set_counter_max: NULL argument");
+    *counter_max = s->counter_max;
     return KH_OK;
 }
 
@@ -287,7 +295,7 @@ extern "C" int kh_set_counts(kh_ctx* c, const kh_set* in, uint32_t value, kh_set
     if (!c || !in || !out) return kh_fail(KH_E_ARG, "kh_set_counts: NULL argument");
     if (value == 0) return kh_fail(KH_E_ARG, "set_counts 0 would empty the database");
     buf_ref(in->kb);
-    *out = make_set(in->k, in->n, in->kb, in->koff, nullptr, 0, value);
+    *out = make_set(in->k, in->n, in->kb, in->koff, nullptr, 0, value, std::max<u32>(value, KH_KMC_DEFAULT_CS));
     return KH_OK;
 }
 
@@ -441,7 +449,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         const u64 n = incl - prev;
         buf_ref(okeys);
         if (ocnt) buf_ref(ocnt);
-        out_sets[i] = make_set(k, n, okeys, prev * kb, ocnt, prev * 4, 1);
+        out_sets[i] = make_set(k, n, okeys, prev * kb, ocnt, prev * 4, 1, cs);
         c->stat.distinct += n;
         prev = incl;
     }
@@ -501,7 +509,7 @@ static int run_setop(kh_ctx* c, const std::vector<const kh_set*>& in, int op, in
         HIPCHK(hipMemsetAsync(d_hist.b->p, 0, 8 * (u64)hist_len, st));
     }
     if (total == 0) {
-        *out = make_set(k, 0, nullptr, 0, nullptr, 0, 1);
+        *out = make_set(k, 0, nullptr, 0, nullptr, 0, 1, cs);
         if (hist) memset(hist, 0, 8 * (size_t)hist_len);
         return KH_OK;
     }
@@ -563,7 +571,7 @@ static int run_setop(kh_ctx* c, const std::vector<const kh_set*>& in, int op, in
         const u64 n = tail[0] & ((1ull << 62) - 1);
         buf_ref(okeys);
         buf_ref(ocnt);
-        *out = make_set(k, n, okeys, 0, ocnt, 0, 1);
+        *out = make_set(k, n, okeys, 0, ocnt, 0, 1, cs);
         c->stat.setop_out += n;
         return KH_OK;
     }
@@ -657,10 +665,10 @@ extern "C" int kh_set_download(kh_ctx* c, const kh_set* s, uint64_t* keys, uint3
 }
 
 int kh_set_from_mixed_host(kh_ctx* c, int k, u64 n, const void* keys_mixed_sorted, const u32* counts,
-                           u32 uniform, kh_set** out) {
+                           u32 uniform, u32 counter_max, kh_set** out) {
     const int W = k <= 32 ? 1 : 2;
     const size_t kb = 8 * (size_t)W;
-    if (!n) { *out = make_set(k, 0, nullptr, 0, nullptr, 0, uniform); return KH_OK; }
+    if (!n) { *out = make_set(k, 0, nullptr, 0, nullptr, 0, uniform, counter_max); return KH_OK; }
     DevBuf* kbuf = c->buf_alloc(kb * n);
     DevBuf* cbuf = counts ? c->buf_alloc(4 * n) : nullptr;
     struct Guard { DevBuf *a, *b; ~Guard() { buf_unref(a); buf_unref(b); } } guard{kbuf, cbuf};
@@ -670,7 +678,7 @@ int kh_set_from_mixed_host(kh_ctx* c, int k, u64 n, const void* keys_mixed_sorte
     HIPCHK(hipStreamSynchronize(c->st));
     buf_ref(kbuf);
     if (cbuf) buf_ref(cbuf);
-    *out = make_set(k, n, kbuf, 0, cbuf, 0, uniform);
+    *out = make_set(k, n, kbuf, 0, cbuf, 0, uniform, counter_max);
     return KH_OK;
 }
 
@@ -700,7 +708,7 @@ extern "C" int kh_set_upload(kh_ctx* c, int k, uint64_t n, const uint64_t* keys,
         if (i && memcmp(&sk[i * W], &sk[(i - 1) * W], 8 * W) == 0)
             return kh_fail(KH_E_ARG, "kh_set_upload: keys are not distinct");
     }
-    return kh_set_from_mixed_host(c, k, n, sk.data(), counts ? sc.data() : nullptr, 1, out);
+    return kh_set_from_mixed_host(c, k, n, sk.data(), counts ? sc.data() : nullptr, 1, KH_KMC_DEFAULT_CS, out);
 }
 
 extern "C" int kh_set_from_device(kh_ctx* c, int k, uint64_t n, const void* keys_mixed, const uint32_t* counts,

@@ -65,6 +65,7 @@ struct kh_set {
     DevBuf* cb;    // nullptr => uniform counter
     size_t coff;
     u32 uniform;
+    u32 counter_max;   // saturation value the counters were produced with (histogram range)
     const void* keys_ptr() const { return kb ? static_cast<const u8*>(kb->p) + koff : nullptr; }
     const u32* counts_ptr() const {
         return cb ? reinterpret_cast<const u32*>(static_cast<const u8*>(cb->p) + coff) : nullptr;
@@ -73,4 +74,4 @@ struct kh_set {
 
 int kh_fail(int code, const char* fmt, ...);
 int kh_set_from_mixed_host(kh_ctx* c, int k, u64 n, const void* keys_mixed_sorted, const u32* counts,
-                           u32 uniform, kh_set** out);
+                           u32 uniform, u32 counter_max, kh_set** out);

@@ -96,7 +96,7 @@ struct KhFileHeader {
     uint32_t words;       // W
     uint32_t has_counts;
     uint32_t uniform;
-    uint32_t reserved;
+    uint32_t counter_max;
     uint64_t n;
     uint64_t mix_id;      // fingerprint of the key mixing function
 };
@@ -158,6 +158,7 @@ extern "C" int kh_save(kh_ctx* c, const kh_set* s, const char* prefix) {
     h.words = (uint32_t)s->W;
     h.has_counts = s->cb ? 1 : 0;
     h.uniform = s->uniform;
+    h.counter_max = s->counter_max;
     h.n = s->n;
     h.mix_id = mix_fingerprint();
     const std::string pre = std::string(prefix) + ".kmc_pre", suf = std::string(prefix) + ".kmc_suf";
@@ -200,7 +201,7 @@ extern "C" int kh_load(kh_ctx* c, const char* prefix, kh_set** out) {
     fclose(fs);
     if (!ok) return kh_fail(KH_E_FORMAT, "%s is truncated or not a khoice_amd database", suf.c_str());
     return kh_set_from_mixed_host(c, (int)h.k, h.n, keys.data(), h.has_counts ? counts.data() : nullptr,
-                                  h.uniform, out);
+                                  h.uniform, h.counter_max ? h.counter_max : KH_KMC_DEFAULT_CS, out);
 }
 
 // ------------------------------------------------------------------------------ text outputs

@@ -69,6 +69,7 @@ def load_library(path: Optional[str] = None):
         "kh_dump_sorted": (C.c_int, [vp, vp, C.c_char_p]),
         "kh_set_free": (None, [vp]),
         "kh_set_info": (C.c_int, [vp, u64p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), u32p]),
+        "kh_set_counter_max": (C.c_int, [vp, u32p]),
         "kh_set_download": (C.c_int, [vp, vp, vp, vp]),
         "kh_set_upload": (C.c_int, [vp, C.c_int, C.c_uint64, vp, vp, C.POINTER(vp)]),
         "kh_set_device_ptrs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
@@ -95,7 +96,8 @@ ABI_SYMBOLS = [
     "kh_ctx_create", "kh_ctx_destroy", "kh_last_error", "kh_device_count", "kh_stats",
     "kh_profile_enable", "kh_stats_reset", "kh_sync", "kh_trim", "kh_build_batch", "kh_build_fasta",
     "kh_read_fasta", "kh_free_host", "kh_set_counts", "kh_union_sum", "kh_simple", "kh_histogram",
-    "kh_histogram_file", "kh_dump_sorted", "kh_set_free", "kh_set_info", "kh_set_download",
+    "kh_histogram_file", "kh_dump_sorted", "kh_set_free", "kh_set_info", "kh_set_counter_max",
+    "kh_set_download",
     "kh_set_upload", "kh_set_device_ptrs", "kh_set_from_device", "kh_set_partition_bounds",
     "kh_save", "kh_load", "kh_exp1_run", "kh_mix_host", "kh_unmix_host",
 ]
@@ -139,6 +141,11 @@ class KmerSet:
         _check(self._e._lib.kh_set_info(self._h, C.byref(n), C.byref(k), C.byref(w), C.byref(hc), C.byref(uni)))
         return {"n": n.value, "k": k.value, "words": w.value, "has_counts": bool(hc.value),
                 "uniform": uni.value}
+
+    def counter_max(self) -> int:
+        v = C.c_uint32()
+        _check(self._e._lib.kh_set_counter_max(self._h, C.byref(v)))
+        return v.value
 
     def __len__(self):
         return self.info()["n"]
@@ -309,9 +316,9 @@ class Engine:
         """`kmc_tools simple A B intersect OUT [-oc<mode>]` (exp_type_2.smk:363-365)."""
         return self.simple(a, b, INTERSECT, mode, cs)
 
-    def kmers_subtract(self, a, b):
+    def kmers_subtract(self, a, b, cs=KMC_DEFAULT_CS):
         """`kmc_tools simple A B kmers_subtract OUT` (exp_type_2.smk:377-379)."""
-        return self.simple(a, b, KMERS_SUBTRACT, "left", NO_MAX)
+        return self.simple(a, b, KMERS_SUBTRACT, "left", cs)
 
     # -- transfer / files
     def upload(self, k: int, keys: np.ndarray, counts: Optional[np.ndarray] = None) -> KmerSet:

@@ -6,6 +6,7 @@ suite read the committed fixtures, never the reference.  Nothing from the refere
 is copied: the fixtures hold inputs and the outputs the reference computed for them.
 
 Sources executed:
+  * workflow/rules/exp_type_1.smk:26-84    parse-time writer of the `kmc_tools complex` files
   * workflow/rules/exp_type_1.smk:115-150  summarize_histogram_type1
   * workflow/rules/exp_type_1.smk:199-231  body of rule within_group_union_analysis
   * workflow/rules/exp_type_1.smk:268-297  body of rule across_group_union_analysis
@@ -174,6 +175,36 @@ def gen_csv(s1, rng):
             "within_csv": within_csv, "across_csv": across_csv}
 
 
+def gen_complex_ops():
+    """Run the parse-time section exp_type_1.smk:26-84 in a scratch WORK_ROOT."""
+    body = _lines(f"{REF}/workflow/rules/exp_type_1.smk", 26, 84)
+    k_values, num_datasets = ["7", "31"], 3
+    listing = {"1": ["only.fna.gz"], "2": ["b.fna.gz", "a.fna.gz", "notes.txt"],
+               "3": ["g3.fna.gz", "g1.fna.gz", "g2.fna.gz", "g0.fna.gz"]}
+    files = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            for num, names in listing.items():
+                os.makedirs(f"data/dataset_{num}")
+                for n in names:
+                    open(f"data/dataset_{num}/{n}", "w").close()
+            real = os.listdir
+            fake_os = type("FakeOs", (), {})()
+            for attr in dir(os):
+                setattr(fake_os, attr, getattr(os, attr))
+            fake_os.listdir = lambda p: list(listing[os.path.basename(os.path.normpath(p)).split("_")[1]]) \
+                if os.path.basename(os.path.normpath(p)).startswith("dataset_") else real(p)
+            exec(body, {"exp_type": 1, "k_values": k_values, "num_datasets": num_datasets, "os": fake_os})
+            for d, _, names in os.walk("complex_ops"):
+                for n in names:
+                    files[os.path.join(d, n)] = open(os.path.join(d, n)).read()
+        finally:
+            os.chdir(cwd)
+    return {"k_values": k_values, "num_datasets": num_datasets, "listing": listing, "files": files}
+
+
 def main():
     s1, s2, ml = load_reference()
     rng = random.Random(0x6B686F696365)
@@ -182,6 +213,7 @@ def main():
         "summarize_type2.json": gen_type2(s2, rng),
         "canonical_kmers.json": gen_canonical(ml, rng),
         "exp1_csv.json": gen_csv(s1, rng),
+        "complex_ops.json": gen_complex_ops(),
     }
     for name, obj in out.items():
         with open(os.path.join(HERE, name), "w") as fh:

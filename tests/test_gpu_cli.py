@@ -1,0 +1,154 @@
+"""The drop-in boundary on a real MI355X: bin/kmc and bin/kmc_tools driven with exactly the
+argv khoice's Snakemake rules use (exp_type_1.smk:156-259, exp_type_2.smk:354-393,
+exp_type_4.smk:247-271), compared with the oracle; BASELINE configs[0] end to end."""
+import os
+import subprocess
+
+import pytest
+
+from khoice_amd import synth
+from khoice_amd.workflow import exp_type_1 as W
+from oracle import kmer_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    from khoice_amd import build as kbuild
+    kbuild.build_library()
+    kbuild.build_clis()
+
+
+def sh(cmd, cwd, ok=True):
+    env = dict(os.environ, PATH=BIN + os.pathsep + os.environ["PATH"])
+    r = subprocess.run(["bash", "-c", "set -euo pipefail; " + cmd], cwd=cwd, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if ok:
+        assert r.returncode == 0, r.stderr
+    return r
+
+
+def test_cfg1_two_species_one_genome_k21(tmp_path):
+    """BASELINE configs[0]: 2 species x 1 genome (1 Mbp), k = 21, full step_1..step_9 DAG."""
+    root = str(tmp_path)
+    synth.write_dataset_tree(root, 2, 1, 1_000_000)
+    out = W.run(root, [21], 2)            # real bin/kmc, bin/kmc_tools
+    from oracle import c_oracle as CO
+    dbs = []
+    for s in (1, 2):
+        fa = O.read_fasta_bytes(os.path.join(root, f"data/dataset_{s}/sp{s}_g0.fna.gz"))
+        text = "\n".join(O.fasta_records(fa)).encode()
+        dbs.append(CO.count(text, 21).set_counts(1))
+    for s, d in zip((1, 2), dbs):
+        h = CO.union_sum([d], 5000).histogram(65536)
+        want = "".join(f"{c}\t{int(h[c])}\n" for c in range(1, 65536))
+        assert open(os.path.join(root, f"step_4/k_21/dataset_{s}/dataset_{s}_k21_hist.txt")).read() == want
+    h = CO.union_sum(dbs, 5000).histogram(65536)
+    want = "".join(f"{c}\t{int(h[c])}\n" for c in range(1, 65536))
+    assert open(os.path.join(root, "step_8/k_21/all_datasets_k21_hist.txt")).read() == want
+    assert open(os.path.join(root, "final_results_type1/within_datasets_analysis.csv")).read() == out["within"]
+    assert out["within"].splitlines()[1].startswith("group_1,21,1.0,0.0,0.0,0.0,1.0,1.0,")
+    assert out["across"].splitlines()[1].startswith("full_group,21,")
+    # the batched runner writes byte-identical results without launching a process
+    root2 = str(tmp_path / "batched")
+    os.makedirs(root2)
+    synth.write_dataset_tree(root2, 2, 1, 1_000_000)
+    out2 = W.run_batched(root2, [21], 2)
+    assert out2["within"] == out["within"] and out2["across"] == out["across"]
+    for rel in ("step_4/k_21/dataset_2/dataset_2_k21_hist.txt", "step_8/k_21/all_datasets_k21_hist.txt"):
+        assert open(os.path.join(root, rel)).read() == open(os.path.join(root2, rel)).read()
+
+
+def test_multi_genome_groups_and_k_sweep_match_oracle(tmp_path):
+    root = str(tmp_path)
+    synth.write_dataset_tree(root, 2, 3, 40_000)
+    ks = [7, 21, 31, 41]
+    out = W.run_batched(root, ks, 2)
+    # expected CSVs: oracle histograms through the (golden-pinned) summariser
+    exp = str(tmp_path / "expected")
+    for k in ks:
+        unions = []
+        for s in (1, 2):
+            sets = []
+            for g in W.genomes_of(root, s):
+                fa = O.read_fasta_bytes(os.path.join(root, f"data/dataset_{s}/{g}.fna.gz"))
+                sets.append(O.set_counts(O.build(fa, k), 1))
+            u = O.union_sum(sets, 5000)
+            unions.append(O.set_counts(u, 1))
+            p = os.path.join(exp, f"step_4/k_{k}/dataset_{s}/dataset_{s}_k{k}_hist.txt")
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            open(p, "w").write(O.histogram_text(u, 65535))
+            assert open(os.path.join(root, f"step_4/k_{k}/dataset_{s}/dataset_{s}_k{k}_hist.txt")).read() == \
+                O.histogram_text(u, 65535)
+        p = os.path.join(exp, f"step_8/k_{k}/all_datasets_k{k}_hist.txt")
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        open(p, "w").write(O.histogram_text(O.union_sum(unions, 5000), 65535))
+    os.makedirs(os.path.join(exp, "data"), exist_ok=True)
+    for s in (1, 2):
+        os.symlink(os.path.join(root, f"data/dataset_{s}"), os.path.join(exp, f"data/dataset_{s}"))
+    want = W._csv_stage(exp, [str(k) for k in ks], 2)
+    assert out["within"] == want["within"] and out["across"] == want["across"]
+    # rule-per-process run of one k gives the same step_4 file
+    root3 = str(tmp_path / "procs")
+    os.makedirs(root3)
+    synth.write_dataset_tree(root3, 2, 3, 40_000)
+    W.run(root3, [31], 2)
+    for s in (1, 2):
+        rel = f"step_4/k_31/dataset_{s}/dataset_{s}_k31_hist.txt"
+        assert open(os.path.join(root3, rel)).read() == open(os.path.join(root, rel)).read()
+
+
+def test_exp_type_2_and_4_call_forms(tmp_path):
+    """simple intersect -ocsum / kmers_subtract (exp_type_2.smk:363-379) and dump -s
+    (exp_type_4.smk:255-257) with the reference's argv."""
+    root = str(tmp_path)
+    k = 21
+    rng_recs = synth.genome_records(1, 0, 30_000), synth.genome_records(1, 1, 30_000)
+    for name, recs in zip(("pivot", "other"), rng_recs):
+        open(os.path.join(root, name + ".fa"), "wb").write(synth.fasta_bytes(recs))
+    os.makedirs(os.path.join(root, "tmp"))
+    sh(f"kmc -fm -m64 -k{k} -ci1 pivot.fa pivot tmp/", root)
+    sh(f"kmc -fm -m64 -k{k} -ci1 other.fa other tmp/", root)
+    sh("kmc_tools transform pivot set_counts 1 pivot.transformed", root)
+    sh("kmc_tools transform other set_counts 1 other.transformed", root)
+    sh("kmc_tools simple pivot.transformed other.transformed intersect inter -ocsum", root)
+    sh("kmc_tools simple pivot.transformed other.transformed kmers_subtract  sub ", root)
+    sh("kmc_tools transform inter histogram inter.hist.txt", root)
+    sh("kmc_tools transform sub histogram sub.hist.txt", root)
+    sh("kmc_tools transform pivot dump -s pivot.txt", root)
+    sh("kmc_tools transform inter dump -s inter.txt", root)
+    da = O.build(synth.fasta_bytes(rng_recs[0]), k)
+    db = O.build(synth.fasta_bytes(rng_recs[1]), k)
+    sa, sb = O.set_counts(da, 1), O.set_counts(db, 1)
+    assert open(os.path.join(root, "pivot.txt")).read() == O.dump_sorted_text(da, k)
+    assert open(os.path.join(root, "inter.txt")).read() == O.dump_sorted_text(O.intersect(sa, sb, "sum"), k)
+    assert open(os.path.join(root, "inter.hist.txt")).read() == O.histogram_text(O.intersect(sa, sb, "sum"), 255)
+    assert open(os.path.join(root, "sub.hist.txt")).read() == O.histogram_text(O.kmers_subtract(sa, sb), 255)
+    # the reference's own invariants on these histograms (exp_type_2.smk:183-184)
+    from khoice_amd import summarize as S
+    sub = S.read_histogram_file(os.path.join(root, "sub.hist.txt"))
+    inter = S.read_histogram_file(os.path.join(root, "inter.hist.txt"))
+    assert inter[0] == 0 and sum(sub[1:]) == 0
+    S.summarize_histogram_type2(sub, inter, 2, False, k)
+    # src/merge_lists.py:14-33 consumes the dumps by `line.split()`: first/second column
+    first = open(os.path.join(root, "pivot.txt")).readline().split()
+    assert len(first) == 2 and len(first[0]) == k and first[1].isdigit()
+
+
+def test_cli_errors_are_loud_and_leave_no_outputs(tmp_path):
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "tmp"))
+    r = sh("kmc -fm -m64 -k21 -ci1 missing.fna.gz out tmp/", root, ok=False)
+    assert r.returncode != 0 and "missing.fna.gz" in r.stderr
+    assert not os.path.exists(os.path.join(root, "out.kmc_pre"))
+    r = sh("kmc_tools transform nothing set_counts 1 out2", root, ok=False)
+    assert r.returncode != 0 and not os.path.exists(os.path.join(root, "out2.kmc_pre"))
+    r = sh("kmc -fm -b -k21 x y tmp/", root, ok=False)
+    assert r.returncode != 0 and "not supported" in r.stderr
+    open(os.path.join(root, "bad.kmc_pre"), "wb").write(b"KMCP not ours")
+    open(os.path.join(root, "bad.kmc_suf"), "wb").write(b"KMCS")
+    r = sh("kmc_tools transform bad histogram h.txt", root, ok=False)
+    assert r.returncode != 0 and "khoice_amd database" in r.stderr
