@@ -84,8 +84,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; khoice_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("KHOICE_BENCH_FORCE_DIST") == "1"   # rehearse the N>1 path on 1 GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- synthetic inputs, resident in HBM
@@ -100,18 +104,19 @@ def main():
     gen_s = time.time() - t0
 
     eng = E.Engine(local_rank)
-    if world > 1:
+    use_dist = world > 1 or force_dist
+    if use_dist:
         from khoice_amd import dist as kdist
 
     def step():
-        if world == 1:
+        if not use_dist:
             return eng.exp1_run(seqs, group_of, args.k, cs=5000, hist_len=5001)
         return kdist.exp1_step(eng, seqs, group_of, args.k, cs=5000, hist_len=5001)
 
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -206,7 +211,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -135,6 +135,17 @@ int kh_set_upload(kh_ctx *ctx, int k, uint64_t n, const uint64_t *keys, const ui
 /* raw device views for zero-copy exchange (multi-GPU): mixed keys sorted ascending,
  * counts NULL when uniform.  Valid until the set is freed. */
 int kh_set_device_ptrs(const kh_set *set, const void **keys_mixed, const uint32_t **counts);
+/* copy the raw storage (mixed keys in storage order; counters, materialised when uniform) into
+ * caller-owned DEVICE buffers of n*W*8 and n*4 bytes: the send side of the exchange */
+int kh_set_export_device(kh_ctx *ctx, const kh_set *set, void *keys_out, uint32_t *counts_out);
+/* the same for elements [lo, hi); stream-ordered on the ctx stream (kh_sync before use elsewhere) */
+int kh_set_export_range(kh_ctx *ctx, const kh_set *set, uint64_t lo, uint64_t hi, void *keys_out,
+                        uint32_t *counts_out);
+/* zero-copy handle over caller-owned device arrays (mixed keys ascending and distinct; counts may
+ * be NULL => every counter == uniform): the receive side of the exchange.  The arrays must stay
+ * alive and unchanged until kh_set_free. */
+int kh_set_wrap_device(kh_ctx *ctx, int k, uint64_t n, const void *keys_mixed, const uint32_t *counts,
+                       uint32_t uniform, kh_set **out);
 /* wrap device arrays of already mixed, sorted, distinct keys (copied into the library) */
 int kh_set_from_device(kh_ctx *ctx, int k, uint64_t n, const void *keys_mixed,
                        const uint32_t *counts, kh_set **out);
@@ -158,6 +169,8 @@ int kh_load(kh_ctx *ctx, const char *prefix, kh_set **out);
  *   distinct_per_seq [nseq]              distinct canonical k-mers of each genome
  *   group_sets     optional [ngroups]: the step_3 group unions (caller frees)
  *   across_set     optional: the step_7 union (caller frees)
+ * When across_hist and across_set are both NULL steps 7-8 are skipped (multi-GPU callers run
+ * them after the exchange of the group sets).
  */
 int kh_exp1_run(kh_ctx *ctx, int nseq, const uint8_t *const *seqs, const uint64_t *lens,
                 int on_device, const int *group_of, int ngroups, int k, uint32_t cs,

@@ -100,7 +100,7 @@ void buf_ref(DevBuf* b) { if (b) b->refs.fetch_add(1); }
 void buf_unref(DevBuf* b) {
     if (!b) return;
     if (b->refs.fetch_sub(1) == 1) {
-        b->ctx->pool.release(b->p, b->bytes);
+        if (b->ctx) b->ctx->pool.release(b->p, b->bytes);   // borrowed buffers have no ctx
         delete b;
     }
 }
@@ -732,6 +732,53 @@ extern "C" int kh_set_from_device(kh_ctx* c, int k, uint64_t n, const void* keys
     return KH_OK;
 }
 
+extern "C" int kh_set_export_range(kh_ctx* c, const kh_set* s, uint64_t lo, uint64_t hi, void* keys_out,
+                                   uint32_t* counts_out) {
+    if (!c || !s) return kh_fail(KH_E_ARG, "kh_set_export_range: NULL argument");
+    if (lo > hi || hi > s->n) return kh_fail(KH_E_ARG, "kh_set_export_range: [%llu,%llu) outside [0,%llu)",
+                                             (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)s->n);
+    HIPCHK(hipSetDevice(c->dev));
+    const u64 n = hi - lo;
+    if (!n) return KH_OK;
+    const size_t kb = 8 * (size_t)s->W;
+    if (keys_out)
+        HIPCHK(hipMemcpyAsync(keys_out, static_cast<const u8*>(s->keys_ptr()) + lo * kb, kb * n,
+                              hipMemcpyDeviceToDevice, c->st));
+    if (counts_out) {
+        if (s->cb) HIPCHK(hipMemcpyAsync(counts_out, s->counts_ptr() + lo, 4 * n, hipMemcpyDeviceToDevice, c->st));
+        else kh_launch_fill_u32(counts_out, n, s->uniform, c->st);
+    }
+    return KH_OK;   // stream-ordered: call kh_sync before another stream reads the buffers
+}
+extern "C" int kh_set_export_device(kh_ctx* c, const kh_set* s, void* keys_out, uint32_t* counts_out) {
+    if (!c || !s) return kh_fail(KH_E_ARG, "kh_set_export_device: NULL argument");
+    int r = kh_set_export_range(c, s, 0, s->n, keys_out, counts_out);
+    if (r != KH_OK) return r;
+    HIPCHK(hipStreamSynchronize(c->st));
+    return KH_OK;
+}
+// zero-copy view of caller-owned device arrays (mixed keys ascending, distinct); the caller
+// keeps them alive and unchanged for the life of the handle
+extern "C" int kh_set_wrap_device(kh_ctx* c, int k, uint64_t n, const void* keys_mixed, const uint32_t* counts,
+                                  uint32_t uniform, kh_set** out) {
+    if (!c || !out || (n && !keys_mixed)) return kh_fail(KH_E_ARG, "kh_set_wrap_device: bad argument");
+    KHCHK(check_k(k));
+    if (!n) { *out = make_set(k, 0, nullptr, 0, nullptr, 0, uniform ? uniform : 1); return KH_OK; }
+    auto borrow = [&](const void* p, size_t bytes) {
+        DevBuf* b = new DevBuf;
+        b->p = const_cast<void*>(p);
+        b->bytes = bytes;
+        b->refs = 1;
+        b->ctx = nullptr;   // not owned: never returned to the pool
+        return b;
+    };
+    const int W = k <= 32 ? 1 : 2;
+    DevBuf* kbuf = borrow(keys_mixed, 8 * (size_t)W * n);
+    DevBuf* cbuf = counts ? borrow(counts, 4 * n) : nullptr;
+    *out = make_set(k, n, kbuf, 0, cbuf, 0, uniform ? uniform : 1);
+    return KH_OK;
+}
+
 extern "C" int kh_set_partition_bounds(kh_ctx* c, const kh_set* s, uint32_t nparts, uint64_t* bounds) {
     if (!c || !s || !bounds || !nparts) return kh_fail(KH_E_ARG, "kh_set_partition_bounds: bad argument");
     HIPCHK(hipSetDevice(c->dev));
@@ -783,9 +830,12 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
         r = kh_set_counts(c, unions[g], 1, &usets[g]);
         if (r != KH_OK) { cleanup(); return r; }
     }
-    // steps 7+8
-    r = kh_union_sum(c, usets.data(), ngroups, cs, &across, across_hist, hist_len);
-    if (r != KH_OK) { cleanup(); return r; }
+    // steps 7+8 (skipped when the caller wants neither output: the multi-GPU path does them
+    // after exchanging the group sets, khoice_amd/dist.py)
+    if (across_hist || across_set) {
+        r = kh_union_sum(c, usets.data(), ngroups, cs, &across, across_hist, hist_len);
+        if (r != KH_OK) { cleanup(); return r; }
+    }
     if (group_sets)
         for (int g = 0; g < ngroups; ++g) { group_sets[g] = unions[g]; unions[g] = nullptr; }
     if (across_set) { *across_set = across; across = nullptr; }

@@ -1,0 +1,141 @@
+"""Multi-GPU experiment type 1: one process per MI355X, torch.distributed over RCCL/xGMI.
+
+Sharding
+  * steps 1-6 (per-genome sets, within-group unions, step_5 histograms) are independent per
+    group: every rank owns whole groups and needs NO communication.
+  * steps 7-8 (in how many groups does a k-mer occur) are the one real exchange:
+      1. the mixed key space is cut into `world` equal-width, order-preserving slots; a set is
+         sorted by mixed key, so what rank j owns of a group set is one contiguous slice;
+      2. all-to-all of the slices (one variable-size all_to_all_single of 8W-byte keys; the
+         counters travel too only when some set carries any) — a full-mesh pattern that uses
+         every xGMI link at once, never a ring over a bitmap;
+      3. each rank union-sums the slices it received in ONE pass (counter = number of groups
+         holding the key, saturating at cs) with the histogram fused in;
+      4. all-reduce (sum) of the small histogram.
+    Mixed keys are uniform, so the slots are balanced without sampling.
+
+The exchange is written against a small `ops` interface so that the very same code runs under
+`gloo` on CPU in the tests (with an oracle-backed stand-in for the engine).
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class EngineOps:
+    """Engine side of the exchange for real runs: sets live in HBM, the exchange buffers are
+    torch tensors on the same device, received slices are wrapped without copying."""
+
+    def __init__(self, eng, device: torch.device):
+        self.eng = eng
+        self.device = device
+
+    def words(self, k):
+        return 1 if k <= 32 else 2
+
+    def has_counts(self, s):
+        i = s.info()
+        return bool(i["has_counts"]) or i["uniform"] != 1
+
+    def partition_bounds(self, s, nparts):
+        return s.partition_bounds(nparts)
+
+    def export_range(self, s, lo, hi, keys_t, counts_t):
+        s.export_range(lo, hi, keys_t.data_ptr(), counts_t.data_ptr() if counts_t is not None else None)
+
+    def flush(self):
+        self.eng.sync()                       # export copies ran on the engine's stream
+
+    def wrap(self, k, n, keys_t, counts_t):
+        return self.eng.wrap_device(k, n, keys_t.data_ptr(), counts_t.data_ptr() if counts_t is not None else None)
+
+    def before_wrap(self):
+        torch.cuda.synchronize(self.device)   # the collective ran on torch's stream
+
+    def union_hist(self, sets, cs, hist_len):
+        return self.eng.union_sum(sets, cs, hist_len=hist_len)
+
+
+def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_len: int,
+                              group=None) -> np.ndarray:
+    """Global step_8 histogram: hist[c] = number of distinct k-mers that occur in exactly c of
+    ALL ranks' groups (c saturating at cs).  Collective: every rank must call it."""
+    world = dist.get_world_size(group)
+    dev = ops.device
+    w = ops.words(k)
+    g_local = len(group_sets)
+    # slot boundaries of every local group set: bounds[g][j] .. bounds[g][j+1] goes to rank j
+    bounds = [np.asarray(ops.partition_bounds(s, world), dtype=np.int64) for s in group_sets]
+    meta = torch.tensor([g_local, int(any(ops.has_counts(s) for s in group_sets))], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    g_all = [int(m[0]) for m in metas]
+    with_counts = any(int(m[1]) for m in metas)
+    g_max = max(max(g_all), 1)
+    # slice lengths, padded to g_max per destination
+    send_len = np.zeros((world, g_max), dtype=np.int64)
+    for g in range(g_local):
+        send_len[:, g] = bounds[g][1:] - bounds[g][:-1]
+    sl = torch.from_numpy(send_len.reshape(-1)).to(dev)
+    rl = torch.empty(world * g_max, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rl, sl, group=group)
+    recv_len = rl.cpu().numpy().reshape(world, g_max)
+    send_n = send_len.sum(axis=1)
+    recv_n = recv_len.sum(axis=1)
+    # pack: destination-major, group-minor
+    skeys = torch.empty(int(send_n.sum()) * w, dtype=torch.int64, device=dev)
+    scnt = torch.empty(int(send_n.sum()), dtype=torch.int32, device=dev) if with_counts else None
+    off = 0
+    for j in range(world):
+        for g in range(g_local):
+            n = int(send_len[j, g])
+            if n:
+                ops.export_range(group_sets[g], int(bounds[g][j]), int(bounds[g][j + 1]),
+                                 skeys[off * w:(off + n) * w], scnt[off:off + n] if with_counts else None)
+            off += n
+    ops.flush()
+    rkeys = torch.empty(int(recv_n.sum()) * w, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rkeys, skeys, output_split_sizes=[int(n) * w for n in recv_n],
+                           input_split_sizes=[int(n) * w for n in send_n], group=group)
+    rcnt = None
+    if with_counts:
+        rcnt = torch.empty(int(recv_n.sum()), dtype=torch.int32, device=dev)
+        dist.all_to_all_single(rcnt, scnt, output_split_sizes=[int(n) for n in recv_n],
+                               input_split_sizes=[int(n) for n in send_n], group=group)
+    ops.before_wrap()
+    # every received slice is sorted, distinct and inside this rank's slot: union them in one pass
+    slices = []
+    off = 0
+    for i in range(world):
+        for g in range(g_max):
+            n = int(recv_len[i, g])
+            if n:
+                slices.append(ops.wrap(k, n, rkeys[off * w:(off + n) * w],
+                                       rcnt[off:off + n] if with_counts else None))
+            off += n
+    if slices:
+        _, hist = ops.union_hist(slices, cs, hist_len)
+        hist = np.asarray(hist)
+    else:
+        hist = np.zeros(hist_len, dtype=np.uint64)
+    del slices
+    ht = torch.from_numpy(hist.astype(np.int64)).to(dev)
+    dist.all_reduce(ht, op=dist.ReduceOp.SUM, group=group)
+    return ht.cpu().numpy().astype(np.uint64)
+
+
+def exp1_step(eng, seqs, group_of: Sequence[int], k: int, cs: int = 5000, hist_len: int = 5001,
+              group=None):
+    """One benchmark step on N GPUs: steps 1-6 locally, steps 7-8 through the exchange.
+    Returns the same dict as Engine.exp1_run (across_hist is the GLOBAL histogram)."""
+    device = torch.device("cuda", eng.device)
+    res = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len, want_sets=True, across=False)
+    ops = EngineOps(eng, device)
+    gsets = [s.set_counts(1) for s in res["group_sets"]]
+    res["across_hist"] = across_groups_distributed(ops, gsets, k, cs, hist_len, group)
+    del res["group_sets"]
+    return res

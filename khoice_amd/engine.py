@@ -74,6 +74,9 @@ def load_library(path: Optional[str] = None):
         "kh_set_upload": (C.c_int, [vp, C.c_int, C.c_uint64, vp, vp, C.POINTER(vp)]),
         "kh_set_device_ptrs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "kh_set_from_device": (C.c_int, [vp, C.c_int, C.c_uint64, vp, vp, C.POINTER(vp)]),
+        "kh_set_export_device": (C.c_int, [vp, vp, vp, vp]),
+        "kh_set_export_range": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, vp]),
+        "kh_set_wrap_device": (C.c_int, [vp, C.c_int, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(vp)]),
         "kh_set_partition_bounds": (C.c_int, [vp, vp, C.c_uint32, u64p]),
         "kh_save": (C.c_int, [vp, vp, C.c_char_p]),
         "kh_load": (C.c_int, [vp, C.c_char_p, C.POINTER(vp)]),
@@ -98,7 +101,8 @@ ABI_SYMBOLS = [
     "kh_read_fasta", "kh_free_host", "kh_set_counts", "kh_union_sum", "kh_simple", "kh_histogram",
     "kh_histogram_file", "kh_dump_sorted", "kh_set_free", "kh_set_info", "kh_set_counter_max",
     "kh_set_download",
-    "kh_set_upload", "kh_set_device_ptrs", "kh_set_from_device", "kh_set_partition_bounds",
+    "kh_set_upload", "kh_set_device_ptrs", "kh_set_from_device", "kh_set_export_device",
+    "kh_set_export_range", "kh_set_wrap_device", "kh_set_partition_bounds",
     "kh_save", "kh_load", "kh_exp1_run", "kh_mix_host", "kh_unmix_host",
 ]
 
@@ -170,6 +174,14 @@ class KmerSet:
         else:
             order = np.lexsort((keys[:, 0], keys[:, 1]))
         return keys[order], counts[order]
+
+    def export_device(self, keys_ptr: int, counts_ptr: int):
+        """Copy mixed keys / counters into caller-owned device buffers (exchange send side)."""
+        _check(self._e._lib.kh_set_export_device(self._e._ctx, self._h, keys_ptr, counts_ptr))
+
+    def export_range(self, lo: int, hi: int, keys_ptr: int, counts_ptr: Optional[int]):
+        """Stream-ordered copy of elements [lo, hi); call Engine.sync() before other streams read."""
+        _check(self._e._lib.kh_set_export_range(self._e._ctx, self._h, lo, hi, keys_ptr, counts_ptr))
 
     def device_ptrs(self):
         kp, cp = C.c_void_p(), C.c_void_p()
@@ -337,6 +349,13 @@ class Engine:
         _check(self._lib.kh_set_from_device(self._ctx, k, n, keys_ptr, counts_ptr, C.byref(out)))
         return KmerSet(self, out.value)
 
+    def wrap_device(self, k: int, n: int, keys_ptr: int, counts_ptr: Optional[int] = None,
+                    uniform: int = 1) -> KmerSet:
+        """Zero-copy set over caller-owned device arrays (kept alive by the caller)."""
+        out = C.c_void_p()
+        _check(self._lib.kh_set_wrap_device(self._ctx, k, n, keys_ptr, counts_ptr, uniform, C.byref(out)))
+        return KmerSet(self, out.value)
+
     def load(self, prefix: str) -> KmerSet:
         out = C.c_void_p()
         _check(self._lib.kh_load(self._ctx, prefix.encode(), C.byref(out)))
@@ -344,7 +363,7 @@ class Engine:
 
     # -- fused experiment type 1
     def exp1_run(self, seqs: Sequence, group_of: Sequence[int], k: int, cs: int = 5000,
-                 hist_len: int = 5001, want_sets: bool = False):
+                 hist_len: int = 5001, want_sets: bool = False, across: bool = True):
         """Device side of exp_type_1.smk:156-259 for one k.  Returns a dict with
         within_hist[ngroups, hist_len], across_hist[hist_len], distinct_per_seq[nseq]
         (and the group / across sets when want_sets)."""
@@ -353,18 +372,21 @@ class Engine:
         ng = max(group_of) + 1
         gof = (C.c_int * n)(*[int(g) for g in group_of])
         within = np.zeros((ng, hist_len), dtype=np.uint64)
-        across = np.zeros(hist_len, dtype=np.uint64)
         distinct = np.zeros(n, dtype=np.uint64)
         gsets = (C.c_void_p * ng)()
         aset = C.c_void_p()
+        do_across = across
+        across = np.zeros(hist_len, dtype=np.uint64)
         _check(self._lib.kh_exp1_run(self._ctx, n, ptrs, _u64p(lens), on_dev, gof, ng, k, cs,
-                                     _u64p(within), _u64p(across), hist_len, _u64p(distinct),
-                                     gsets if want_sets else None,
-                                     C.byref(aset) if want_sets else None))
-        res = {"within_hist": within, "across_hist": across, "distinct_per_seq": distinct}
+                                     _u64p(within), _u64p(across) if do_across else None, hist_len,
+                                     _u64p(distinct), gsets if want_sets else None,
+                                     C.byref(aset) if (want_sets and do_across) else None))
+        res = {"within_hist": within, "across_hist": across if do_across else None,
+               "distinct_per_seq": distinct}
         if want_sets:
             res["group_sets"] = [KmerSet(self, gsets[i]) for i in range(ng)]
-            res["across_set"] = KmerSet(self, aset.value)
+            if do_across:
+                res["across_set"] = KmerSet(self, aset.value)
         return res
 
 

@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    # On a GPU box bring torch's HIP context up BEFORE the engine library touches the device:
+    # the reverse order leaves torch.cuda unable to see the GPU in the same process.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def load_golden(name):
     with open(os.path.join(GOLDEN, name)) as fh:
         return json.load(fh)

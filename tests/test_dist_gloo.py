@@ -1,0 +1,124 @@
+"""The N>1 path on CPU: khoice_amd.dist.across_groups_distributed under world_size-2 and -3 gloo,
+with an oracle-backed stand-in for the engine (tests only).  Checks the exchange plumbing:
+slot bounds, variable-size all-to-all, received slices inside the owner's slot, histogram
+all-reduce, against the single-process oracle answer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from khoice_amd import synth
+from oracle import kmer_oracle as O
+
+K = 21
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleOps:
+    """numpy stand-in: a set is (mixed keys uint64[n] ascending, counts uint32[n] or None)."""
+    device = torch.device("cpu")
+
+    def __init__(self, k, rank=0, world=1):
+        self.k, self.rank, self.world = k, rank, world
+
+    def words(self, k):
+        return 1
+
+    def has_counts(self, s):
+        return s[1] is not None
+
+    def slot(self, keys, nparts):
+        top32 = keys >> np.uint64(2 * self.k - 32)
+        return (top32 * np.uint64(nparts)) >> np.uint64(32)
+
+    def partition_bounds(self, s, nparts):
+        return np.searchsorted(self.slot(s[0], nparts), np.arange(nparts + 1), side="left")
+
+    def export_range(self, s, lo, hi, keys_t, counts_t):
+        keys_t.copy_(torch.from_numpy(s[0][lo:hi].view(np.int64).copy()))
+        if counts_t is not None:
+            c = s[1][lo:hi] if s[1] is not None else np.ones(hi - lo, dtype=np.uint32)
+            counts_t.copy_(torch.from_numpy(c.view(np.int32).copy()))
+
+    def flush(self):
+        pass
+
+    def before_wrap(self):
+        pass
+
+    def wrap(self, k, n, keys_t, counts_t):
+        keys = keys_t.numpy().view(np.uint64).copy()
+        assert (self.slot(keys, self.world) == self.rank).all()      # inside this rank's slot
+        assert keys.size < 2 or (keys[1:] > keys[:-1]).all()         # sorted and distinct
+        return keys, (counts_t.numpy().view(np.uint32).copy() if counts_t is not None else None)
+
+    def union_hist(self, sets, cs, hist_len):
+        keys = np.concatenate([s[0] for s in sets])
+        cnts = np.concatenate([s[1] if s[1] is not None else np.ones(s[0].size, dtype=np.uint32) for s in sets])
+        u, inv = np.unique(keys, return_inverse=True)
+        c = np.zeros(u.size, dtype=np.int64)
+        np.add.at(c, inv, cnts.astype(np.int64))
+        c = np.minimum(c, cs)
+        return (u, c.astype(np.uint32)), np.bincount(np.minimum(c, hist_len - 1), minlength=hist_len).astype(np.uint64)
+
+
+def group_db(species, n_genomes=2, length=4000):
+    anc = synth.ancestor(species, length)
+    dbs = [O.set_counts(O.count_records([s.decode() for _, s in synth.genome_records(species, g, length, anc)], K), 1)
+           for g in range(n_genomes)]
+    return O.set_counts(O.union_sum(dbs, 5000), 1)
+
+
+def to_mixed(db):
+    from khoice_amd import engine as E
+    keys = np.array(sorted(db), dtype=np.uint64)
+    mixed = np.array([int(E.mix_host(K, np.array([v], dtype=np.uint64))[0]) for v in keys], dtype=np.uint64)
+    return np.sort(mixed), None
+
+
+def worker(rank, world, port, groups_per_rank, with_counts, q):
+    from khoice_amd import dist as kdist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        ops = OracleOps(K, rank, world)
+        first = 1 + sum(groups_per_rank[:rank])
+        mine = [to_mixed(group_db(first + g)) for g in range(groups_per_rank[rank])]
+        if with_counts and mine:      # make one rank's sets carry counters: they must travel
+            mine[0] = (mine[0][0], np.ones(mine[0][0].size, dtype=np.uint32))
+        hist = kdist.across_groups_distributed(ops, mine, K, 5000, 64)
+        q.put((rank, hist.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout,with_counts", [([3, 3], False), ([2, 0, 3], True)])
+def test_across_groups_exchange_matches_single_process(layout, with_counts):
+    from khoice_amd import build as kbuild
+    kbuild.build_library()
+    world = len(layout)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, layout, with_counts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = sum(layout)
+    want = O.histogram(O.union_sum([group_db(1 + g) for g in range(total)], 5000), 63)
+    for _, h in got:
+        assert h == want
+    assert sum(want[2:]) > 0          # the shared block makes some k-mers multi-group

@@ -298,3 +298,28 @@ def test_full_size_properties(eng):
     # species are independent apart from the shared block: cross-species overlap is small
     x = eng.intersect(sets[0].set_counts(1), sets[2].set_counts(1), "sum")
     assert 0 < len(x) < 0.1 * len(a)
+
+
+def test_distributed_step_world1_matches_local(eng):
+    """khoice_amd.dist over RCCL with a single rank: the exchange degenerates to a self
+    all-to-all but exercises export / import / union of received slices on the device."""
+    import torch
+    import torch.distributed as dist
+    from khoice_amd import dist as kdist
+    from khoice_amd import synth
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for k in (21, 41):
+            items = synth.species_set(3, 2, 60_000)
+            seqs = [t for _, _, t in items]
+            group_of = [s - 1 for s, _, _ in items]
+            want = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=5001)
+            got = kdist.exp1_step(eng, seqs, group_of, k, cs=5000, hist_len=5001)
+            assert (got["across_hist"] == want["across_hist"]).all()
+            assert (got["within_hist"] == want["within_hist"]).all()
+            assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+    finally:
+        dist.destroy_process_group()
