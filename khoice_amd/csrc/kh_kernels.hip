@@ -714,7 +714,7 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
 // Only a bucket with more DISTINCT keys than the pair capacity cannot be handled; that
 // raises KH_ERR_CAPACITY (the host then re-plans the batch with more buckets).
 template <int W>
-__global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
+__global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_bucket_sort_rle(
     const KmerKey<W>* __restrict__ part, const u64* __restrict__ bstart,
     const KhSeg* __restrict__ segs, u32 nseg, u32 cap, int k, KmerKey<W>* __restrict__ out_keys,
     u32* __restrict__ out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs) {
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS) void k_bucket_sort_rle(
     // pair-mode carve (oversize path): keys[capp] | pay[capp] inside the key region
     const u32 capp = ((cap * 8u * W) / (8u * W + 4u)) & ~63u;
     u32* pay = reinterpret_cast<u32*>(lds_raw + (size_t)capp * 8 * W);
-    constexpr int E = (W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2) / KH_SORT_THREADS;
+    constexpr int E = ((W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2) + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
 
     const u32 tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) {
@@ -862,7 +862,7 @@ __device__ __forceinline__ long long combine_counters(int mode, long long a, lon
 // key is simply the length of its run, no payload array needed (the step_3 / step_7 case,
 // exp_type_1.smk:182,250).  PAY=true: payload = counter | (operand index > 0) << 31.
 template <int W, bool PAY>
-__global__ __launch_bounds__(KH_SORT_THREADS) void k_setop(
+__global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_setop(
     const KhSetView* __restrict__ sets, u32 nsets, const u64* __restrict__ bounds, u32 nranges,
     u32 cap, int k, int op, int mode, u32 cs, KmerKey<W>* __restrict__ out_keys,
     u32* __restrict__ out_counts, KhLookback lb, unsigned long long* __restrict__ hist,
