@@ -14,6 +14,9 @@
 //                                ordered single-pass output
 // All integer work; bounded by HBM bandwidth, not by MFMA (none is used).
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
 #include "kh_launch.h"
 
 #define KH_WAVE 64
@@ -236,6 +239,159 @@ __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
     if (!SCATTER) {
         __syncthreads();
         for (u32 i = tid; i < nb; i += 256) row[i] = cur[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass B with write combining (W = 1).  The direct form above stores every key as a lone 8-byte
+// write; the lines are evicted from L2 before their neighbours arrive and HBM sees 3.3x the
+// bytes (measured: WRITE_SIZE 6.6 GB for 2.0 GB of keys).  Here a sub-tile's keys are first
+// counting-sorted by bucket inside LDS (through registers, in place), so that consecutive lanes
+// then store consecutive keys of one bucket run: the same bytes reach HBM in far fewer, fuller
+// sectors.  Needs 64 KiB of staging, so it is used while the genome's cursor table is small
+// enough for two workgroups per CU (host check); otherwise k_extract<1, true> runs.
+// ------------------------------------------------------------------------------------------
+size_t kh_extract_staged_lds_bytes(u32 nb_alloc) {
+    return (size_t)KH_SUBTILE * 8 + (size_t)nb_alloc * 4 + ((size_t)nb_alloc + 4) * 4 +
+           (size_t)KH_CODE_WORDS * 4 + (size_t)KH_CODE_WORDS * 2 + 8 + 64;
+}
+
+__global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict__ seq,
+                                                          const KhSeg* __restrict__ segs,
+                                                          const KhTile* __restrict__ tiles,
+                                                          u32 nb_alloc, int k,
+                                                          const u32* __restrict__ thist,
+                                                          const u64* __restrict__ bstart,
+                                                          KmerKey<1>* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    KmerKey<1>* stage = reinterpret_cast<KmerKey<1>*>(lds_raw);                 // [KH_SUBTILE]
+    u32* cur = reinterpret_cast<u32*>(lds_raw + (size_t)KH_SUBTILE * 8);         // [nb_alloc] global cursors
+    u32* sub = cur + nb_alloc;                                                   // [nb_alloc + 4] sub-tile counts
+    u32* code = sub + nb_alloc + 4;
+    u16* bad16 = reinterpret_cast<u16*>(code + KH_CODE_WORDS);
+    u32* wsum = reinterpret_cast<u32*>(bad16 + KH_CODE_WORDS + 4);               // [8] scan scratch
+
+    const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const KhTile t = tiles[blockIdx.x];
+    const KhSeg sg = segs[t.seg];
+    const u32 nb = sg.nbuckets;
+    const u32* row = thist + sg.thist_base + (u64)t.tile_in_seg * nb;
+    for (u32 i = tid; i < nb; i += 256) cur[i] = row[i];
+    const u64 part_base = bstart[sg.bucket_base];
+    const Roller<1> roller(k);
+    const u8* sbase = seq + sg.seq_off;
+    const u64 tile_pos0 = (u64)t.tile_in_seg * KH_TILE;
+    const u32 per = (nb + 255) / 256;   // scan entries per thread (host guarantees <= 8)
+
+    for (int sb = 0; sb < KH_SUBTILES_PER_TILE; ++sb) {
+        const u64 p0 = tile_pos0 + (u64)sb * KH_SUBTILE;
+        if (p0 >= sg.npos) break;   // uniform over the block
+        __syncthreads();            // previous sub-tile fully flushed, cursors advanced
+        for (u32 w = tid; w < (u32)KH_CODE_WORDS; w += 256) {
+            const u64 b0 = p0 + 16ull * w;
+            u32 codes = 0, bad = 0xffffu;
+            if (b0 < sg.len) {
+                const uint4 v = *reinterpret_cast<const uint4*>(sbase + b0);
+                decode16(v, codes, bad);
+                const u64 left = sg.len - b0;
+                if (left < 16) bad |= (0xffffu << (u32)left) & 0xffffu;
+            }
+            code[w] = codes;
+            bad16[w] = (u16)bad;
+        }
+        for (u32 i = tid; i <= nb; i += 256) sub[i] = 0;
+        __syncthreads();
+        // ---- A: extract; the key of this thread's start position st is staged at 256*st + tid
+        u32 vm = 0;   // which of the 32 start positions gave a key
+        {
+            KmerKey<1> f = key_zero<1>(), r = key_zero<1>();
+            int run = 0;
+            const int last_base = 31 + k - 1;
+            for (int wi = 0; wi * 16 <= last_base; ++wi) {
+                const u32 cw = code[2 * tid + wi];
+                const u32 bw = bad16[2 * tid + wi];
+#pragma unroll 4
+                for (int j = 0; j < 16; ++j) {
+                    const int u = wi * 16 + j;
+                    const u32 c = (cw >> (2 * j)) & 3u;
+                    roller.push(f, r, c);
+                    run = ((bw >> j) & 1u) ? 0 : run + 1;
+                    const int st = u - (k - 1);
+                    if (st >= 0 && st < 32 && run >= k) {
+                        KmerKey<1> can = key_lt(r, f) ? r : f;
+                        can = kh_mix(can, k);
+                        stage[256 * st + tid] = can;   // position-major: conflict-free, and
+                        vm |= 1u << st;                // phase C reads back exactly these
+                        atomicAdd(&sub[kh_slot<1>(can, k, nb)], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- B: exclusive scan of the bucket counts, in place (sub[b] = first staged index)
+        {
+            u32 c[8], sum = 0;
+#pragma unroll
+            for (u32 j = 0; j < 8; ++j) {
+                const u32 b = tid * per + j;
+                c[j] = (j < per && b < nb) ? sub[b] : 0u;
+                sum += c[j];
+            }
+            u32 incl = sum;
+#pragma unroll
+            for (int off = 1; off < KH_WAVE; off <<= 1) {
+                const u32 v = __shfl_up(incl, off);
+                if (lane >= (u32)off) incl += v;
+            }
+            if (lane == KH_WAVE - 1) wsum[wid] = incl;
+            __syncthreads();
+            u32 run = incl - sum;
+            for (u32 w = 0; w < wid; ++w) run += wsum[w];
+#pragma unroll
+            for (u32 j = 0; j < 8; ++j) {
+                const u32 b = tid * per + j;
+                if (j < per && b < nb) sub[b] = run;
+                run += c[j];
+            }
+            if (tid == 255) sub[nb] = run;   // total staged keys (threads past nb add nothing)
+        }
+        __syncthreads();
+        // ---- C/D: in-place counting sort by bucket through registers
+        {
+            KmerKey<1> key[32];
+            u32 pos2[16];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                key[j] = key_zero<1>();
+                u32 at = 0;
+                if (vm & (1u << j)) {
+                    key[j] = stage[256u * j + tid];
+                    at = atomicAdd(&sub[kh_slot<1>(key[j], k, nb)], 1u);
+                }
+                if (j & 1) pos2[j >> 1] |= at << 16; else pos2[j >> 1] = at;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (vm & (1u << j)) stage[(pos2[j >> 1] >> (16 * (j & 1))) & 0xffffu] = key[j];
+        }
+        __syncthreads();
+        // ---- E: flush; sub[b] now holds the END of bucket b's staged run
+        {
+            const u32 nvalid = sub[nb];
+#pragma unroll 4
+            for (int j = 0; j < 32; ++j) {
+                const u32 p = 256u * j + tid;
+                if (p < nvalid) {
+                    const KmerKey<1> key = stage[p];
+                    const u32 b = kh_slot<1>(key, k, nb);
+                    const u32 first = b ? sub[b - 1] : 0u;
+                    part[part_base + cur[b] + (p - first)] = key;
+                }
+            }
+        }
+        __syncthreads();
+        for (u32 b = tid; b < nb; b += 256) cur[b] += sub[b] - (b ? sub[b - 1] : 0u);
     }
 }
 
@@ -1076,6 +1232,14 @@ void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, co
                        u32 ntiles, u32 nb_alloc, int k, u32* thist, const u64* bstart, void* part,
                        hipStream_t st) {
     if (!ntiles) return;
+    if (scatter && W == 1 && nb_alloc <= 2048 && kh_extract_staged_lds_bytes(nb_alloc) <= 80 * 1024 &&
+        !getenv("KHOICE_DIRECT_SCATTER")) {
+        const size_t lds2 = kh_extract_staged_lds_bytes(nb_alloc);
+        allow_lds(k_extract_staged, lds2);
+        hipLaunchKernelGGL(k_extract_staged, dim3(ntiles), dim3(256), lds2, st, seq, segs, tiles, nb_alloc, k,
+                           thist, bstart, reinterpret_cast<KmerKey<1>*>(part));
+        return;
+    }
     const size_t lds = kh_extract_lds_bytes(nb_alloc);
 #define KH_EX(WW, SC)                                                                           \
     do {                                                                                        \

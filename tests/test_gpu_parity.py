@@ -323,3 +323,16 @@ def test_distributed_step_world1_matches_local(eng):
             assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
     finally:
         dist.destroy_process_group()
+
+
+def test_direct_and_staged_scatter_agree(eng, monkeypatch):
+    """pass B has two forms (LDS write combining / direct stores); both must give the same sets."""
+    rng = random.Random(321)
+    seqs = [random_dna(rng, n, "ACGTN").encode() for n in (200_000, 90_000)]
+    a = eng.build_batch(seqs, 31)
+    monkeypatch.setenv("KHOICE_DIRECT_SCATTER", "1")
+    b = eng.build_batch(seqs, 31)
+    for x, y in zip(a, b):
+        kx, cx = x.download()
+        ky, cy = y.download()
+        assert (kx == ky).all() and (cx == cy).all()
