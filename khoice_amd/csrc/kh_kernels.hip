@@ -625,18 +625,23 @@ __device__ __forceinline__ u32 bin_base(const u32* bins, u32 f) {
     return (bins[f >> 1] >> (16 * (f & 1))) & 0xffffu;
 }
 
+__device__ __forceinline__ void distribute_clear(u32* bins, u32* dirty, u32* scratch) {
+    const u32 tid = threadIdx.x;
+    for (u32 i = tid; i <= (u32)KH_FINE_BINS / 2; i += KH_SORT_THREADS) bins[i] = 0;
+    for (u32 i = tid; i < (u32)KH_FINE_BINS / 32; i += KH_SORT_THREADS) dirty[i] = 0;
+    if (tid == 0) scratch[20] = 0;   // work-list length
+}
+
 template <int W, bool PAY, int E>
 __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E], const u32 n,
                                 KmerKey<W>* s, u32* pay, u32* bins, u32* dirty, u32* wl,
                                 u32* scratch, int k, u32 nslots, u32 q) {
+    // precondition: distribute_clear() ran and a barrier followed (the kernels fold it into the
+    // barrier that broadcasts the ticket)
     constexpr u32 NT = KH_SORT_THREADS;
     constexpr u32 WORDS = KH_FINE_BINS / 2;
     constexpr u32 PER = WORDS / NT;   // packed words scanned per thread
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    for (u32 i = tid; i <= WORDS; i += NT) bins[i] = 0;
-    for (u32 i = tid; i < (u32)KH_FINE_BINS / 32; i += NT) dirty[i] = 0;
-    if (tid == 0) scratch[20] = 0;   // work-list length
-    __syncthreads();
     u32 fr[E];   // fine bin << 16 | arrival rank inside the bin
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -805,7 +810,8 @@ __device__ __forceinline__ void table_scan(u32* tab) {
 
 template <int W, int E, class Eval, class Sink>
 __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab, Eval eval, Sink sink,
-                         KhLookback lb, const u32 q, u32* scratch, const bool all_kept) {
+                         KhLookback lb, const u32 q, u32* scratch, const bool all_kept,
+                         const bool keys_only = false) {
     constexpr u32 NT = KH_SORT_THREADS;
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const u64 lt_mask = (1ull << lane) - 1ull;
@@ -826,12 +832,37 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
     // when no run can be dropped the slot's output count is already known: publish it now so
     // that it is visible to the successors by the time they look back
     if (all_kept && q != 0 && tid == 0) lb_store(&lb.desc[q], KH_LB_AGG | (u64)d);
+    if (all_kept && keys_only) {
+        // plain sets (no counter array, nothing dropped): every run head is an output and its
+        // rank is already known, so the run table and the second ranking are skipped
+        u32 base[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) base[e] = tab[e * 8 + wid] + lr[e];
+        const u64 ob = lookback_block(lb.desc, q, (u64)d, lb.err, scratch);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (flags & (1u << e)) sink(ob + base[e], s[(u32)e * NT + tid], 1u);
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if (flags & (1u << e)) hstart[tab[e * 8 + wid] + lr[e]] = (u16)((u32)e * NT + tid);
     if (tid == 0) hstart[d] = (u16)n;
     __syncthreads();
     KH_STAMP(q, 6);
+    if (all_kept) {
+        // every run is kept: output rank = run index, only the counters remain to be evaluated
+        const u64 ob = lookback_block(lb.desc, q, (u64)d, lb.err, scratch);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const u32 r = (u32)e * NT + tid;
+            if (r < d) {
+                const u32 h0 = hstart[r];
+                sink(ob + r, s[h0], eval(h0, (u32)hstart[r + 1]));
+            }
+        }
+        return;
+    }
     // ---- (2) counters of the runs, kept runs ranked
     u32 cnt[E];
 #pragma unroll
@@ -886,6 +917,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
     constexpr int E = ((W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2) + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
 
     const u32 tid = threadIdx.x, nt = blockDim.x;
+    distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
     if (tid == 0) {
         const u32 t = atomicAdd(lb.ticket, 1u);
         scratch[16] = t;
@@ -930,7 +962,8 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
             const u32 c = h1 - h0;
             return (c >= ci && c <= cx) ? c : 0u;
         };
-        rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch, ci <= 1u && cx == 0xffffffffu);
+        rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch, ci <= 1u && cx == 0xffffffffu,
+                       out_counts == nullptr);
         return;
     }
 
@@ -1036,6 +1069,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
                              : (W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2);
     constexpr int E = (CAPC + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
     const u32 tid = threadIdx.x, nt = blockDim.x, lane = lane_id();
+    distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
     if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
     __syncthreads();
     const u32 q = scratch[16];
