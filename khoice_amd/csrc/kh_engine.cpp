@@ -479,103 +479,146 @@ extern "C" int kh_build_batch(kh_ctx* c, int nseq, const uint8_t* const* seqs, c
 }
 
 // ------------------------------------------------------------------------------ set ops
-static int run_setop(kh_ctx* c, const std::vector<const kh_set*>& in, int op, int mode, u32 cs,
-                     kh_set** out, uint64_t* hist, u32 hist_len) {
-    const int nsets = (int)in.size();
-    const int k = in[0]->k, W = in[0]->W;
-    const size_t kb = 8 * (size_t)W;
-    hipStream_t st = c->st;
-    for (auto* s : in)
-        if (s->k != k) return kh_fail(KH_E_KMISMATCH, "operands built with different k (%d vs %d)", k, s->k);
+// One set operation as an asynchronous job: setop_launch() only enqueues work on the ctx stream
+// (kernels + the small device-to-host copies of the result size / histogram); setop_finish()
+// is called after a stream synchronisation, turns the result into a handle and re-plans with
+// smaller slots in the (rare) case a slot overflowed LDS.  Independent operations can thus be
+// enqueued back to back and share one synchronisation (kh_exp1_run does that for the groups).
+struct SetopJob {
+    kh_ctx* c = nullptr;
+    std::vector<const kh_set*> in;
+    int op = 0, mode = 0, k = 0, W = 1;
+    u32 cs = 0, hist_len = 0, cap = 0, nranges = 0;
+    uint64_t* hist = nullptr;
+    bool pay = false, empty = false;
+    u64 total = 0, target = 0;
+    DevBuf *okeys = nullptr, *ocnt = nullptr, *d_views = nullptr, *d_bounds = nullptr, *d_lb = nullptr,
+           *d_hist = nullptr;
+    u64 tail[2] = {0, 0};
+    std::vector<KhSetView> views;   // host copy: must outlive the asynchronous upload
+    ~SetopJob() {
+        buf_unref(okeys); buf_unref(ocnt); buf_unref(d_views); buf_unref(d_bounds); buf_unref(d_lb);
+        buf_unref(d_hist);
+    }
+};
+#define JOB_ALLOC(field, bytes)                                                              \
+    do {                                                                                     \
+        buf_unref(j.field);                                                                  \
+        j.field = c->buf_alloc(bytes);                                                       \
+        if (!j.field) return kh_fail(KH_E_NOMEM, "device allocation of %zu bytes failed", (size_t)(bytes)); \
+    } while (0)
 
-    bool pay = !(op == KH_OP_UNION && mode == KH_OC_SUM);
-    u64 total = 0;
-    std::vector<KhSetView> views(nsets);
+static int setop_prepare(SetopJob& j) {
+    kh_ctx* c = j.c;
+    const int nsets = (int)j.in.size();
+    j.k = j.in[0]->k;
+    j.W = j.in[0]->W;
+    for (auto* s : j.in)
+        if (s->k != j.k) return kh_fail(KH_E_KMISMATCH, "operands built with different k (%d vs %d)", j.k, s->k);
+    j.pay = !(j.op == KH_OP_UNION && j.mode == KH_OC_SUM);
+    j.total = 0;
+    std::vector<KhSetView>& views = j.views;
+    views.resize(nsets);
     for (int g = 0; g < nsets; ++g) {
-        views[g].keys = in[g]->n ? in[g]->keys_ptr() : nullptr;
-        views[g].counts = in[g]->counts_ptr();
-        views[g].n = in[g]->n;
-        views[g].uniform = in[g]->uniform;
+        views[g].keys = j.in[g]->n ? j.in[g]->keys_ptr() : nullptr;
+        views[g].counts = j.in[g]->counts_ptr();
+        views[g].n = j.in[g]->n;
+        views[g].uniform = j.in[g]->uniform;
         views[g].pad = 0;
-        if (in[g]->cb || in[g]->uniform != 1) pay = true;
-        total += in[g]->n;
+        if (j.in[g]->cb || j.in[g]->uniform != 1) j.pay = true;
+        j.total += j.in[g]->n;
     }
     c->stat.setops++;
-    c->stat.setop_in += total;
+    c->stat.setop_in += j.total;
+    if (j.hist) JOB_ALLOC(d_hist, 8 * (u64)j.hist_len);
+    j.empty = j.total == 0;
+    if (j.empty) return KH_OK;
+    j.cap = j.W == 1 ? (j.pay ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_W1) : (j.pay ? KH_SORT_CAP_PAY_W2 : KH_SORT_CAP_W2);
+    j.target = (u64)j.cap * 83 / 100;   // slots are Poisson-tight: mean fill 83 % of LDS capacity
+    JOB_ALLOC(okeys, 8 * (size_t)j.W * j.total);
+    JOB_ALLOC(ocnt, 4 * j.total);
+    JOB_ALLOC(d_views, sizeof(KhSetView) * nsets);
+    HIPCHK(hipMemcpyAsync(j.d_views->p, views.data(), sizeof(KhSetView) * nsets, hipMemcpyHostToDevice, c->st));
+    return KH_OK;
+}
 
-    Tmp d_hist;
-    if (hist) {
-        TMP_ALLOC(d_hist, c, 8 * (u64)hist_len);
-        HIPCHK(hipMemsetAsync(d_hist.b->p, 0, 8 * (u64)hist_len, st));
-    }
-    if (total == 0) {
-        *out = make_set(k, 0, nullptr, 0, nullptr, 0, 1, cs);
-        if (hist) memset(hist, 0, 8 * (size_t)hist_len);
+static int setop_launch(SetopJob& j) {
+    kh_ctx* c = j.c;
+    hipStream_t st = c->st;
+    if (j.empty) return KH_OK;
+    const int nsets = (int)j.in.size();
+    const u64 nr64 = std::max<u64>(1, (j.total + j.target - 1) / j.target);
+    if (nr64 > 0x7fffffffull) return kh_fail(KH_E_ARG, "set operation too large for one launch");
+    j.nranges = (u32)nr64;
+    JOB_ALLOC(d_bounds, 8 * ((u64)j.nranges + 1) * nsets);
+    JOB_ALLOC(d_lb, 8 * (u64)j.nranges + 64);
+    KhLookback lb;
+    lb.desc = reinterpret_cast<u64*>(j.d_lb->p);
+    lb.ticket = reinterpret_cast<u32*>(lb.desc + j.nranges);
+    lb.err = lb.ticket + 1;
+    HIPCHK(hipMemsetAsync(j.d_lb->p, 0, 8 * (u64)j.nranges + 64, st));
+    if (j.hist) HIPCHK(hipMemsetAsync(j.d_hist->p, 0, 8 * (u64)j.hist_len, st));
+#ifdef KH_STAMPS
+    Tmp d_stamps;
+    TMP_ALLOC(d_stamps, c, 128 * (u64)j.nranges);
+    HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * (u64)j.nranges, st));
+    kh_debug_set_stamps(d_stamps.as<u64>());
+#endif
+    c->prof_begin(KC_RANGE_BOUNDS);
+    kh_launch_range_bounds(j.W, reinterpret_cast<KhSetView*>(j.d_views->p), nsets, j.nranges, j.k,
+                           reinterpret_cast<u64*>(j.d_bounds->p), st);
+    c->prof_end();
+    c->prof_begin(KC_SETOP);
+    kh_launch_setop(j.W, j.pay, j.cap, reinterpret_cast<KhSetView*>(j.d_views->p), nsets,
+                    reinterpret_cast<u64*>(j.d_bounds->p), j.nranges, j.k, j.op, j.mode, j.cs, j.okeys->p,
+                    reinterpret_cast<u32*>(j.ocnt->p), lb,
+                    j.hist ? reinterpret_cast<unsigned long long*>(j.d_hist->p) : nullptr, j.hist_len, st);
+    c->prof_end();
+    HIPCHK(hipGetLastError());
+#ifdef KH_STAMPS
+    report_stamps(c, "setop", d_stamps.b, j.nranges);
+    kh_debug_set_stamps(nullptr);
+#endif
+    HIPCHK(hipMemcpyAsync(j.tail, lb.desc + (j.nranges - 1), 16, hipMemcpyDeviceToHost, st));
+    if (j.hist) HIPCHK(hipMemcpyAsync(j.hist, j.d_hist->p, 8 * (size_t)j.hist_len, hipMemcpyDeviceToHost, st));
+    return KH_OK;
+}
+
+// precondition: the stream was synchronised after setop_launch(j)
+static int setop_finish(SetopJob& j, kh_set** out) {
+    kh_ctx* c = j.c;
+    if (j.empty) {
+        *out = make_set(j.k, 0, nullptr, 0, nullptr, 0, 1, j.cs);
+        if (j.hist) memset(j.hist, 0, 8 * (size_t)j.hist_len);
         return KH_OK;
     }
-    const u32 cap = W == 1 ? (pay ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_W1)
-                           : (pay ? KH_SORT_CAP_PAY_W2 : KH_SORT_CAP_W2);
-    u64 target = (u64)cap * 83 / 100;   // slots are Poisson-tight: mean fill 83 % of LDS capacity
-    DevBuf* okeys = c->buf_alloc(kb * total);
-    DevBuf* ocnt = c->buf_alloc(4 * total);
-    struct Guard { DevBuf *a, *b; ~Guard() { buf_unref(a); buf_unref(b); } } guard{okeys, ocnt};
-    if (!okeys || !ocnt) return kh_fail(KH_E_NOMEM, "device allocation failed (set-op output of %llu keys)", (unsigned long long)total);
-
-    Tmp d_views;
-    TMP_ALLOC(d_views, c, sizeof(KhSetView) * nsets);
-    HIPCHK(hipMemcpyAsync(d_views.b->p, views.data(), sizeof(KhSetView) * nsets, hipMemcpyHostToDevice, st));
-
     for (int attempt = 0; attempt < 8; ++attempt) {
-        u64 nr64 = std::max<u64>(1, (total + target - 1) / target);
-        if (nr64 > 0x7fffffffull) return kh_fail(KH_E_ARG, "set operation too large for one launch");
-        const u32 nranges = (u32)nr64;
-        Tmp d_bounds, d_lb;
-        TMP_ALLOC(d_bounds, c, 8 * ((u64)nranges + 1) * nsets);
-        TMP_ALLOC(d_lb, c, 8 * (u64)nranges + 64);
-        KhLookback lb;
-        lb.desc = d_lb.as<u64>();
-        lb.ticket = reinterpret_cast<u32*>(d_lb.as<u64>() + nranges);
-        lb.err = lb.ticket + 1;
-        HIPCHK(hipMemsetAsync(d_lb.b->p, 0, 8 * (u64)nranges + 64, st));
-        if (hist && attempt) HIPCHK(hipMemsetAsync(d_hist.b->p, 0, 8 * (u64)hist_len, st));
-#ifdef KH_STAMPS
-        Tmp d_stamps;
-        TMP_ALLOC(d_stamps, c, 128 * (u64)nranges);
-        HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * (u64)nranges, st));
-        kh_debug_set_stamps(d_stamps.as<u64>());
-#endif
-        c->prof_begin(KC_RANGE_BOUNDS);
-        kh_launch_range_bounds(W, d_views.as<KhSetView>(), nsets, nranges, k, d_bounds.as<u64>(), st);
-        c->prof_end();
-        c->prof_begin(KC_SETOP);
-        kh_launch_setop(W, pay, cap, d_views.as<KhSetView>(), nsets, d_bounds.as<u64>(), nranges, k, op,
-                        mode, cs, okeys->p, reinterpret_cast<u32*>(ocnt->p), lb,
-                        hist ? d_hist.as<unsigned long long>() : nullptr, hist_len, st);
-        c->prof_end();
-        HIPCHK(hipGetLastError());
-#ifdef KH_STAMPS
-        report_stamps(c, "setop", d_stamps.b, nranges);
-        kh_debug_set_stamps(nullptr);
-#endif
-        u64 tail[2];
-        HIPCHK(hipMemcpyAsync(tail, d_lb.as<u64>() + (nranges - 1), 8 + 8, hipMemcpyDeviceToHost, st));
-        if (hist) HIPCHK(hipMemcpyAsync(hist, d_hist.b->p, 8 * (size_t)hist_len, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        const u32 err = reinterpret_cast<const u32*>(&tail[1])[1];
+        const u32 err = reinterpret_cast<const u32*>(&j.tail[1])[1];
         if (err & KH_ERR_SPIN_TIMEOUT) return kh_fail(KH_E_INTERNAL, "look-back spin timed out in set operation");
-        if (err & KH_ERR_CAPACITY) {
-            c->stat.retries++;
-            target = std::max<u64>(16, target / 4);
-            continue;
+        if (!(err & KH_ERR_CAPACITY)) {
+            const u64 n = j.tail[0] & ((1ull << 62) - 1);
+            buf_ref(j.okeys);
+            buf_ref(j.ocnt);
+            *out = make_set(j.k, n, j.okeys, 0, j.ocnt, 0, 1, j.cs);
+            c->stat.setop_out += n;
+            return KH_OK;
         }
-        const u64 n = tail[0] & ((1ull << 62) - 1);
-        buf_ref(okeys);
-        buf_ref(ocnt);
-        *out = make_set(k, n, okeys, 0, ocnt, 0, 1, cs);
-        c->stat.setop_out += n;
-        return KH_OK;
+        c->stat.retries++;
+        j.target = std::max<u64>(16, j.target / 4);
+        KHCHK(setop_launch(j));
+        HIPCHK(hipStreamSynchronize(c->st));
     }
     return kh_fail(KH_E_CAPACITY, "set operation: a key range still overflows LDS after 8 re-plans");
+}
+
+static int run_setop(kh_ctx* c, const std::vector<const kh_set*>& in, int op, int mode, u32 cs,
+                     kh_set** out, uint64_t* hist, u32 hist_len) {
+    SetopJob j;
+    j.c = c; j.in = in; j.op = op; j.mode = mode; j.cs = cs; j.hist = hist; j.hist_len = hist_len;
+    KHCHK(setop_prepare(j));
+    KHCHK(setop_launch(j));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return setop_finish(j, out);
 }
 
 extern "C" int kh_union_sum(kh_ctx* c, const kh_set* const* sets, int nsets, uint32_t cs, kh_set** out,
@@ -818,17 +861,38 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
     if (r != KH_OK) { cleanup(); return r; }
     if (distinct_per_seq)
         for (int i = 0; i < nseq; ++i) distinct_per_seq[i] = gsets[i]->n;
-    // steps 3+4 per group, step 6
-    for (int g = 0; g < ngroups; ++g) {
-        std::vector<const kh_set*> members;
-        for (int i = 0; i < nseq; ++i)
-            if (group_of[i] == g) members.push_back(gsets[i]);
-        if (members.empty()) { cleanup(); return kh_fail(KH_E_ARG, "group %d has no sequences", g); }
-        r = kh_union_sum(c, members.data(), (int)members.size(), cs, &unions[g],
-                         within_hist ? within_hist + (size_t)g * hist_len : nullptr, hist_len);
-        if (r != KH_OK) { cleanup(); return r; }
-        r = kh_set_counts(c, unions[g], 1, &usets[g]);
-        if (r != KH_OK) { cleanup(); return r; }
+    // steps 3+4 per group, step 6: the group unions are independent, so they are all enqueued
+    // before the host waits once
+    {
+        std::vector<SetopJob> jobs(ngroups);
+        for (int g = 0; g < ngroups; ++g) {
+            SetopJob& j = jobs[g];
+            j.c = c; j.op = KH_OP_UNION; j.mode = KH_OC_SUM; j.cs = cs;
+            j.hist = within_hist ? within_hist + (size_t)g * hist_len : nullptr;
+            j.hist_len = hist_len;
+            for (int i = 0; i < nseq; ++i)
+                if (group_of[i] == g) j.in.push_back(gsets[i]);
+            if (j.in.empty()) { cleanup(); return kh_fail(KH_E_ARG, "group %d has no sequences", g); }
+            if ((int)j.in.size() > KH_MAX_INPUT_SETS) {   // beyond one launch's fan-in: the general path
+                r = kh_union_sum(c, j.in.data(), (int)j.in.size(), cs, &unions[g], j.hist, hist_len);
+                if (r != KH_OK) { cleanup(); return r; }
+                j.in.clear();
+                continue;
+            }
+            r = setop_prepare(j);
+            if (r == KH_OK) r = setop_launch(j);
+            if (r != KH_OK) { cleanup(); return r; }
+        }
+        if (hipStreamSynchronize(c->st) != hipSuccess) { cleanup(); return kh_fail(KH_E_HIP, "stream sync failed"); }
+        for (int g = 0; g < ngroups; ++g) {
+            if (jobs[g].in.empty()) continue;
+            r = setop_finish(jobs[g], &unions[g]);
+            if (r != KH_OK) { cleanup(); return r; }
+        }
+        for (int g = 0; g < ngroups; ++g) {
+            r = kh_set_counts(c, unions[g], 1, &usets[g]);
+            if (r != KH_OK) { cleanup(); return r; }
+        }
     }
     // steps 7+8 (skipped when the caller wants neither output: the multi-GPU path does them
     // after exchanging the group sets, khoice_amd/dist.py)
