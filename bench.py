@@ -124,7 +124,7 @@ def main():
     for _ in range(args.warmup):
         res = step()
     eng.stats_reset()
-    eng.profile(True)
+    eng.profile(os.environ.get("KHOICE_BENCH_NOPROF") != "1")
     fence()
     t1 = time.perf_counter()
     for _ in range(args.steps):

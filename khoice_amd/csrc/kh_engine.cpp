@@ -122,8 +122,12 @@ void kh_ctx::prof_begin(int cls) {
     if (!profile) return;
     ProfEvt ev;
     ev.cls = cls;
-    (void)hipEventCreate(&ev.a);
-    (void)hipEventCreate(&ev.b);
+    auto take = [&](hipEvent_t* e) {   // events are recycled: creating one costs microseconds
+        if (!free_events.empty()) { *e = free_events.back(); free_events.pop_back(); }
+        else (void)hipEventCreate(e);
+    };
+    take(&ev.a);
+    take(&ev.b);
     (void)hipEventRecord(ev.a, st);
     evts.push_back(ev);
 }
@@ -140,8 +144,8 @@ void kh_ctx::prof_collect() {
             cls_ms[ev.cls] += ms;
             cls_n[ev.cls] += 1;
         }
-        (void)hipEventDestroy(ev.a);
-        (void)hipEventDestroy(ev.b);
+        free_events.push_back(ev.a);
+        free_events.push_back(ev.b);
     }
     evts.clear();
 }
@@ -186,6 +190,7 @@ extern "C" void kh_ctx_destroy(kh_ctx* c) {
     (void)hipSetDevice(c->dev);
     (void)hipStreamSynchronize(c->st);
     c->prof_collect();
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
     c->pool.trim();
     (void)hipStreamDestroy(c->st);
     delete c;

@@ -47,6 +47,7 @@ struct kh_ctx {
     Stats stat;
     bool profile = false;
     std::vector<ProfEvt> evts;
+    std::vector<hipEvent_t> free_events;
     double cls_ms[KC_COUNT] = {0};
     u64 cls_n[KC_COUNT] = {0};
     DevBuf* buf_alloc(size_t bytes);
