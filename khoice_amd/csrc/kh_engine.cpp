@@ -338,12 +338,14 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
 
     // ---- segment layout
     std::vector<KhSeg> segs(nseq);
+    std::vector<u64> pack_off(nseq);
     std::vector<KhTile> tiles;
     u64 seq_bytes = 0, total_pos = 0, thist_n = 0;
     u32 nb_total = 0, max_nb = 1;
     for (int i = 0; i < nseq; ++i) {
         KhSeg& s = segs[i];
-        s.seq_off = seq_bytes;
+        s.seq = nullptr;
+        pack_off[i] = seq_bytes;
         s.len = lens[i];
         s.npos = lens[i] >= (u64)k ? lens[i] - k + 1 : 0;
         const u64 want_b = std::max<u64>(1, (s.npos + mean - 1) / mean);
@@ -389,10 +391,17 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     }
     struct Guard { DevBuf *a, *b; ~Guard() { buf_unref(a); buf_unref(b); } } guard{okeys, ocnt};
 
+    // device-resident, 16-byte aligned inputs are read in place; anything else is packed into
+    // the aligned batch buffer first
     c->prof_begin(KC_COPY_IN);
     for (int i = 0; i < nseq; ++i) {
+        if (on_device && (reinterpret_cast<uintptr_t>(seqs[i]) & 15) == 0) {
+            segs[i].seq = seqs[i];
+            continue;
+        }
+        segs[i].seq = d_seq.as<u8>() + pack_off[i];
         if (!lens[i]) continue;
-        HIPCHK(hipMemcpyAsync(d_seq.as<u8>() + segs[i].seq_off, seqs[i], lens[i],
+        HIPCHK(hipMemcpyAsync(d_seq.as<u8>() + pack_off[i], seqs[i], lens[i],
                               on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
     HIPCHK(hipMemcpyAsync(d_segs.b->p, segs.data(), sizeof(KhSeg) * nseq, hipMemcpyHostToDevice, st));

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
     if (SCATTER) part_base = bstart[sg.bucket_base];
 
     const Roller<W> roller(k);
-    const u8* sbase = seq + sg.seq_off;
+    const u8* sbase = sg.seq;
     const u64 tile_pos0 = (u64)t.tile_in_seg * KH_TILE;
 
     for (int sub = 0; sub < KH_SUBTILES_PER_TILE; ++sub) {
@@ -198,9 +198,16 @@ __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
             const u64 b0 = p0 + 16ull * w;
             u32 codes = 0, bad = 0xffffu;
             if (b0 < sg.len) {
-                const uint4 v = *reinterpret_cast<const uint4*>(sbase + b0);
-                decode16(v, codes, bad);
                 const u64 left = sg.len - b0;
+                uint4 v;
+                if (left >= 16) {
+                    v = *reinterpret_cast<const uint4*>(sbase + b0);
+                } else {   // last, partial word of the sequence: never touch bytes past its end
+                    u32 w4[4] = {0, 0, 0, 0};
+                    for (u32 i = 0; i < (u32)left; ++i) w4[i >> 2] |= (u32)sbase[b0 + i] << (8 * (i & 3));
+                    v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+                decode16(v, codes, bad);
                 if (left < 16) bad |= (0xffffu << (u32)left) & 0xffffu;
             }
             code[w] = codes;
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
     for (u32 i = tid; i < nb; i += 256) cur[i] = row[i];
     const u64 part_base = bstart[sg.bucket_base];
     const Roller<1> roller(k);
-    const u8* sbase = seq + sg.seq_off;
+    const u8* sbase = sg.seq;
     const u64 tile_pos0 = (u64)t.tile_in_seg * KH_TILE;
     const u32 per = (nb + 255) / 256;   // scan entries per thread (host guarantees <= 8)
 
@@ -291,9 +298,16 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
             const u64 b0 = p0 + 16ull * w;
             u32 codes = 0, bad = 0xffffu;
             if (b0 < sg.len) {
-                const uint4 v = *reinterpret_cast<const uint4*>(sbase + b0);
-                decode16(v, codes, bad);
                 const u64 left = sg.len - b0;
+                uint4 v;
+                if (left >= 16) {
+                    v = *reinterpret_cast<const uint4*>(sbase + b0);
+                } else {   // last, partial word of the sequence: never touch bytes past its end
+                    u32 w4[4] = {0, 0, 0, 0};
+                    for (u32 i = 0; i < (u32)left; ++i) w4[i >> 2] |= (u32)sbase[b0 + i] << (8 * (i & 3));
+                    v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+                decode16(v, codes, bad);
                 if (left < 16) bad |= (0xffffu << (u32)left) & 0xffffu;
             }
             code[w] = codes;

@@ -5,7 +5,7 @@
 
 // one input sequence (genome) of a batched build
 struct KhSeg {
-    u64 seq_off;      // byte offset of base 0 in the batch sequence buffer (16-B aligned)
+    const u8* seq;    // device pointer to base 0 (16-B aligned; bytes past len are never read)
     u64 len;          // bases (bytes)
     u64 npos;         // k-mer start positions: len >= k ? len-k+1 : 0
     u64 thist_base;   // index of tile 0 / bucket 0 in the tile-histogram matrix
