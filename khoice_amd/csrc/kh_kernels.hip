@@ -1136,17 +1136,21 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
     // operand whose slice starts at or before i; all loads of a thread are independent
     KmerKey<W> kreg[E];
     u32 preg[E];
+    u32 ga = 0;   // operand of this thread's current element: found once, then only advanced
+    {
+        u32 gb = nsets;
+        while (gb - ga > 1) {
+            const u32 m = (ga + gb) >> 1;
+            if (soff[m] <= tid) ga = m; else gb = m;
+        }
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         kreg[e] = key_zero<W>();
         preg[e] = 0;
         const u32 i = (u32)e * KH_SORT_THREADS + tid;
         if (i < n) {
-            u32 ga = 0, gb = nsets;
-            while (gb - ga > 1) {
-                const u32 m = (ga + gb) >> 1;
-                if (soff[m] <= i) ga = m; else gb = m;
-            }
+            while (ga + 1 < nsets && soff[ga + 1] <= i) ++ga;
             const u64 idx = sbeg[ga] + (i - soff[ga]);
             kreg[e] = reinterpret_cast<const KmerKey<W>*>(skey[ga])[idx];
             if (PAY) {
