@@ -6,6 +6,7 @@
 Outputs (git-ignored, but they travel to the GPU box with the snapshot):
     khoice_amd/lib/libkhoice_hip.so     HIP engine, gfx950 code objects only
     bin/kmc, bin/kmc_tools              drop-in executables (argv of the 7 call forms)
+    bin/khoice_server                   resident engine the two can forward to ($KHOICE_SERVER)
     oracle/_build/libkh_oracle.so       C restatement used by tests / cpu_baseline only
 """
 from __future__ import annotations
@@ -24,7 +25,8 @@ ARCH = "gfx950"
 
 HIP_SOURCES = ["kh_kernels.hip", "kh_engine.cpp", "kh_io.cpp"]
 HEADERS = ["kh_common.h", "kh_launch.h", "kh_engine.h", os.path.join(ROOT, "include", "khoice_hip.h")]
-CLIS = {"kmc": "kmc_main.cpp", "kmc_tools": "kmc_tools_main.cpp"}
+CLIS = {"kmc": "kmc_main.cpp", "kmc_tools": "kmc_tools_main.cpp", "khoice_server": "kh_server_main.cpp"}
+CLI_COMMON = "kh_cli.cpp"
 
 
 def _hipcc() -> str:
@@ -74,9 +76,11 @@ def build_clis(force: bool = False):
         if not os.path.exists(path):
             continue
         exe = os.path.join(BINDIR, name)
-        if force or _newer(exe, [path, LIB, os.path.join(ROOT, "include", "khoice_hip.h")]):
-            _run([hipcc, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), path, "-o", exe,
-                  "-L", LIBDIR, "-lkhoice_hip", f"-Wl,-rpath,$ORIGIN/../khoice_amd/lib"])
+        common = os.path.join(CSRC, CLI_COMMON)
+        if force or _newer(exe, [path, common, os.path.join(CSRC, "kh_cli.h"), LIB,
+                                 os.path.join(ROOT, "include", "khoice_hip.h")]):
+            _run([hipcc, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC, path, common,
+                  "-o", exe, "-L", LIBDIR, "-lkhoice_hip", f"-Wl,-rpath,$ORIGIN/../khoice_amd/lib"])
         out.append(exe)
     return out
 

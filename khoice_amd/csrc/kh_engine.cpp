@@ -870,21 +870,41 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
         for (auto* s : usets) kh_set_free(s);
         kh_set_free(across);
     };
-    // steps 1+2: build every genome as a plain set
-    int r = kh_build_batch(c, nseq, seqs, lens, on_device, k, 1, KH_NO_MAX, KH_KMC_DEFAULT_CS, 0, gsets.data());
-    if (r != KH_OK) { cleanup(); return r; }
-    if (distinct_per_seq)
-        for (int i = 0; i < nseq; ++i) distinct_per_seq[i] = gsets[i]->n;
-    // steps 3+4 per group, step 6: the group unions are independent, so they are all enqueued
-    // before the host waits once
-    {
-        std::vector<SetopJob> jobs(ngroups);
-        for (int g = 0; g < ngroups; ++g) {
-            SetopJob& j = jobs[g];
+    // Groups are independent until step 7, so they are processed in waves that fit a device
+    // memory budget (all groups at once for the benchmark sizes; wave by wave for inputs whose
+    // k-mers would not fit HBM together): per wave, steps 1+2 build every genome of the wave as
+    // a plain set in ONE batched launch sequence, steps 3+4+6 enqueue the wave's group unions
+    // back to back before the host waits once; the genome sets are released before the next wave.
+    u64 budget = 24ull << 30;   // bases per wave (each costs ~40 bytes of HBM while in flight)
+    if (const char* e = getenv("KHOICE_WAVE_BASES")) budget = std::max<u64>(1, strtoull(e, nullptr, 10));
+    std::vector<u64> group_bases(ngroups, 0);
+    for (int i = 0; i < nseq; ++i) group_bases[group_of[i]] += lens[i];
+    int r = KH_OK;
+    for (int g0 = 0; g0 < ngroups;) {
+        int g1 = g0;
+        u64 acc = 0;
+        while (g1 < ngroups && (g1 == g0 || acc + group_bases[g1] <= budget)) acc += group_bases[g1++];
+        std::vector<int> idx;                       // sequences of groups [g0, g1)
+        for (int i = 0; i < nseq; ++i)
+            if (group_of[i] >= g0 && group_of[i] < g1) idx.push_back(i);
+        std::vector<const uint8_t*> wseqs(idx.size());
+        std::vector<uint64_t> wlens(idx.size());
+        std::vector<kh_set*> wsets(idx.size(), nullptr);
+        for (size_t j = 0; j < idx.size(); ++j) { wseqs[j] = seqs[idx[j]]; wlens[j] = lens[idx[j]]; }
+        r = kh_build_batch(c, (int)idx.size(), wseqs.data(), wlens.data(), on_device, k, 1, KH_NO_MAX,
+                           KH_KMC_DEFAULT_CS, 0, wsets.data());
+        if (r != KH_OK) { cleanup(); return r; }
+        for (size_t j = 0; j < idx.size(); ++j) {
+            gsets[idx[j]] = wsets[j];
+            if (distinct_per_seq) distinct_per_seq[idx[j]] = wsets[j]->n;
+        }
+        std::vector<SetopJob> jobs(g1 - g0);
+        for (int g = g0; g < g1; ++g) {
+            SetopJob& j = jobs[g - g0];
             j.c = c; j.op = KH_OP_UNION; j.mode = KH_OC_SUM; j.cs = cs;
             j.hist = within_hist ? within_hist + (size_t)g * hist_len : nullptr;
             j.hist_len = hist_len;
-            for (int i = 0; i < nseq; ++i)
+            for (int i : idx)
                 if (group_of[i] == g) j.in.push_back(gsets[i]);
             if (j.in.empty()) { cleanup(); return kh_fail(KH_E_ARG, "group %d has no sequences", g); }
             if ((int)j.in.size() > KH_MAX_INPUT_SETS) {   // beyond one launch's fan-in: the general path
@@ -898,15 +918,18 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
             if (r != KH_OK) { cleanup(); return r; }
         }
         if (hipStreamSynchronize(c->st) != hipSuccess) { cleanup(); return kh_fail(KH_E_HIP, "stream sync failed"); }
-        for (int g = 0; g < ngroups; ++g) {
-            if (jobs[g].in.empty()) continue;
-            r = setop_finish(jobs[g], &unions[g]);
+        for (int g = g0; g < g1; ++g) {
+            if (jobs[g - g0].in.empty()) continue;
+            r = setop_finish(jobs[g - g0], &unions[g]);
             if (r != KH_OK) { cleanup(); return r; }
         }
-        for (int g = 0; g < ngroups; ++g) {
+        jobs.clear();
+        for (int g = g0; g < g1; ++g) {
             r = kh_set_counts(c, unions[g], 1, &usets[g]);
             if (r != KH_OK) { cleanup(); return r; }
         }
+        for (int i : idx) { kh_set_free(gsets[i]); gsets[i] = nullptr; }   // genome sets of this wave
+        g0 = g1;
     }
     // steps 7+8 (skipped when the caller wants neither output: the multi-GPU path does them
     // after exchanging the group sets, khoice_amd/dist.py)

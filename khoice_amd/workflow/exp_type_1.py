@@ -186,12 +186,17 @@ def run_batched(work_root: str, k_values: Sequence, num_datasets: int, device: i
     eng = E.Engine(device)
     try:
         genomes = {num: genomes_of(work_root, num) for num in range(1, num_datasets + 1)}
-        texts, group_of, names = [], [], []
+        group_of, names = [], []
         for num in range(1, num_datasets + 1):
             for g in genomes[num]:
-                texts.append(eng.read_fasta(os.path.join(work_root, f"data/dataset_{num}/{g}.fna.gz")))
                 group_of.append(num - 1)
                 names.append((num, g))
+        # host ingest (inflate + FASTA parsing) runs in the library without the GIL: one thread
+        # per file up to the core count
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+            texts = list(pool.map(
+                lambda ng: eng.read_fasta(os.path.join(work_root, f"data/dataset_{ng[0]}/{ng[1]}.fna.gz")), names))
         for k in k_values:
             ki = int(k)
             counted = eng.build_batch(texts, ki, ci=1, with_counts=True)

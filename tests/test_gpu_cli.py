@@ -152,3 +152,40 @@ def test_cli_errors_are_loud_and_leave_no_outputs(tmp_path):
     open(os.path.join(root, "bad.kmc_suf"), "wb").write(b"KMCS")
     r = sh("kmc_tools transform bad histogram h.txt", root, ok=False)
     assert r.returncode != 0 and "khoice_amd database" in r.stderr
+
+
+def test_resident_server_serves_the_same_dag(tmp_path, monkeypatch):
+    """bin/khoice_server: the rule processes become thin clients of ONE engine context
+    (SURVEY §8f next #1); results are byte-identical to stand-alone processes."""
+    import time
+    root = str(tmp_path / "direct")
+    root2 = str(tmp_path / "served")
+    for r in (root, root2):
+        os.makedirs(r)
+        synth.write_dataset_tree(r, 2, 2, 30_000)
+    direct = W.run(root, [21, 31], 2)
+    sock = str(tmp_path / "khoice.sock")
+    srv = subprocess.Popen([os.path.join(BIN, "khoice_server"), sock], stderr=subprocess.PIPE, text=True)
+    try:
+        for _ in range(200):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        assert os.path.exists(sock), "server did not come up"
+        monkeypatch.setenv("KHOICE_SERVER", sock)
+        served = W.run(root2, [21, 31], 2)
+        # errors travel back through the client
+        r = sh("kmc_tools transform nothing histogram h.txt", root2, ok=False)
+        assert r.returncode != 0 and "nothing" in r.stderr
+    finally:
+        subprocess.run([os.path.join(BIN, "khoice_server"), "--stop", sock], timeout=30)
+        srv.wait(timeout=30)
+    assert served["within"] == direct["within"] and served["across"] == direct["across"]
+    assert "served" in srv.stderr.read()
+    for rel in ("step_4/k_31/dataset_1/dataset_1_k31_hist.txt", "step_8/k_21/all_datasets_k21_hist.txt"):
+        assert open(os.path.join(root, rel)).read() == open(os.path.join(root2, rel)).read()
+    # a dead socket path falls back to a local engine
+    monkeypatch.setenv("KHOICE_SERVER", str(tmp_path / "gone.sock"))
+    sh("kmc_tools transform step_3/k_21/dataset_1/dataset_1.transformed.combined histogram again.txt", root2)
+    assert open(os.path.join(root2, "again.txt")).read() == \
+        open(os.path.join(root2, "step_4/k_21/dataset_1/dataset_1_k21_hist.txt")).read()

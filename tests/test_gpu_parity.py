@@ -336,3 +336,18 @@ def test_direct_and_staged_scatter_agree(eng, monkeypatch):
         kx, cx = x.download()
         ky, cy = y.download()
         assert (kx == ky).all() and (cx == cy).all()
+
+
+def test_exp1_group_waves_equal_single_wave(eng, monkeypatch):
+    """kh_exp1_run processes groups in memory-bounded waves; any wave size gives the same result."""
+    from khoice_amd import synth
+    items = synth.species_set(4, 2, 40_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    want = eng.exp1_run(seqs, group_of, 31, cs=5000, hist_len=64)
+    for budget in ("1", "90000", "170000"):      # one group per wave, two per wave, ...
+        monkeypatch.setenv("KHOICE_WAVE_BASES", budget)
+        got = eng.exp1_run(seqs, group_of, 31, cs=5000, hist_len=64)
+        assert (got["within_hist"] == want["within_hist"]).all()
+        assert (got["across_hist"] == want["across_hist"]).all()
+        assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
