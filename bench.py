@@ -83,6 +83,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; khoice_amd has no CPU fallback")
+    if os.environ.get("KHOICE_SHARE_GPU") == "1":   # rehearsal: every rank on device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     force_dist = os.environ.get("KHOICE_BENCH_FORCE_DIST") == "1"   # rehearse the N>1 path on 1 GPU
     if world > 1 or force_dist:
@@ -90,7 +92,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("KHOICE_DIST_BACKEND", "nccl")   # "gloo": rehearsal on a shared GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     # ---- synthetic inputs, resident in HBM
     t0 = time.time()
@@ -136,10 +142,11 @@ def main():
 
     distinct_local = int(res["distinct_per_seq"].sum())
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        cdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        dd = torch.tensor([distinct_local], device="cuda", dtype=torch.int64)
+        dd = torch.tensor([distinct_local], device=cdev, dtype=torch.int64)
         dist.all_reduce(dd, op=dist.ReduceOp.SUM)
         distinct_all = int(dd.item())
     else:

@@ -30,9 +30,21 @@ class EngineOps:
     """Engine side of the exchange for real runs: sets live in HBM, the exchange buffers are
     torch tensors on the same device, received slices are wrapped without copying."""
 
-    def __init__(self, eng, device: torch.device):
+    def __init__(self, eng, device: torch.device, stage_on_host: bool = False):
         self.eng = eng
         self.device = device
+        # rehearsal mode (gloo, several ranks sharing one GPU): collectives run on host copies
+        self.stage_on_host = stage_on_host
+
+    def to_comm(self, t):
+        return t.cpu() if self.stage_on_host else t
+
+    def from_comm(self, t):
+        return t.to(self.device) if self.stage_on_host else t
+
+    @property
+    def comm_device(self):
+        return torch.device("cpu") if self.stage_on_host else self.device
 
     def words(self, k):
         return 1 if k <= 32 else 2
@@ -66,11 +78,14 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
     ALL ranks' groups (c saturating at cs).  Collective: every rank must call it."""
     world = dist.get_world_size(group)
     dev = ops.device
+    cdev = getattr(ops, "comm_device", dev)          # where the collectives run
+    to_comm = getattr(ops, "to_comm", lambda t: t)
+    from_comm = getattr(ops, "from_comm", lambda t: t)
     w = ops.words(k)
     g_local = len(group_sets)
     # slot boundaries of every local group set: bounds[g][j] .. bounds[g][j+1] goes to rank j
     bounds = [np.asarray(ops.partition_bounds(s, world), dtype=np.int64) for s in group_sets]
-    meta = torch.tensor([g_local, int(any(ops.has_counts(s) for s in group_sets))], dtype=torch.int64, device=dev)
+    meta = torch.tensor([g_local, int(any(ops.has_counts(s) for s in group_sets))], dtype=torch.int64, device=cdev)
     metas = [torch.empty_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
     g_all = [int(m[0]) for m in metas]
@@ -80,8 +95,8 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
     send_len = np.zeros((world, g_max), dtype=np.int64)
     for g in range(g_local):
         send_len[:, g] = bounds[g][1:] - bounds[g][:-1]
-    sl = torch.from_numpy(send_len.reshape(-1)).to(dev)
-    rl = torch.empty(world * g_max, dtype=torch.int64, device=dev)
+    sl = torch.from_numpy(send_len.reshape(-1)).to(cdev)
+    rl = torch.empty(world * g_max, dtype=torch.int64, device=cdev)
     dist.all_to_all_single(rl, sl, group=group)
     recv_len = rl.cpu().numpy().reshape(world, g_max)
     send_n = send_len.sum(axis=1)
@@ -98,14 +113,16 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
                                  skeys[off * w:(off + n) * w], scnt[off:off + n] if with_counts else None)
             off += n
     ops.flush()
-    rkeys = torch.empty(int(recv_n.sum()) * w, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(rkeys, skeys, output_split_sizes=[int(n) * w for n in recv_n],
+    rkeys = torch.empty(int(recv_n.sum()) * w, dtype=torch.int64, device=cdev)
+    dist.all_to_all_single(rkeys, to_comm(skeys), output_split_sizes=[int(n) * w for n in recv_n],
                            input_split_sizes=[int(n) * w for n in send_n], group=group)
+    rkeys = from_comm(rkeys)
     rcnt = None
     if with_counts:
-        rcnt = torch.empty(int(recv_n.sum()), dtype=torch.int32, device=dev)
-        dist.all_to_all_single(rcnt, scnt, output_split_sizes=[int(n) for n in recv_n],
+        rcnt = torch.empty(int(recv_n.sum()), dtype=torch.int32, device=cdev)
+        dist.all_to_all_single(rcnt, to_comm(scnt), output_split_sizes=[int(n) for n in recv_n],
                                input_split_sizes=[int(n) for n in send_n], group=group)
+        rcnt = from_comm(rcnt)
     ops.before_wrap()
     # every received slice is sorted, distinct and inside this rank's slot: union them in one pass
     slices = []
@@ -123,7 +140,7 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
     else:
         hist = np.zeros(hist_len, dtype=np.uint64)
     del slices
-    ht = torch.from_numpy(hist.astype(np.int64)).to(dev)
+    ht = torch.from_numpy(hist.astype(np.int64)).to(cdev)
     dist.all_reduce(ht, op=dist.ReduceOp.SUM, group=group)
     return ht.cpu().numpy().astype(np.uint64)
 
@@ -134,7 +151,7 @@ def exp1_step(eng, seqs, group_of: Sequence[int], k: int, cs: int = 5000, hist_l
     Returns the same dict as Engine.exp1_run (across_hist is the GLOBAL histogram)."""
     device = torch.device("cuda", eng.device)
     res = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len, want_sets=True, across=False)
-    ops = EngineOps(eng, device)
+    ops = EngineOps(eng, device, stage_on_host=dist.get_backend(group) == "gloo")
     gsets = [s.set_counts(1) for s in res["group_sets"]]
     res["across_hist"] = across_groups_distributed(ops, gsets, k, cs, hist_len, group)
     del res["group_sets"]
