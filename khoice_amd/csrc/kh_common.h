@@ -139,7 +139,7 @@ constexpr int KH_FINE_BITS = 13;            // fine bins of the in-LDS distribut
 constexpr int KH_FINE_BINS = 1 << KH_FINE_BITS;
 constexpr int KH_FINE_LIMIT = 64;           // fullest fine bin the in-bin repair accepts
 constexpr int KH_WORKLIST = 1024;           // keys of out-of-order bins repaired per slot
-constexpr int KH_MAX_INPUT_SETS = 64;       // fan-in of one set-operation launch
+constexpr int KH_MAX_INPUT_SETS = 128;      // fan-in of one set-operation launch
 constexpr int KH_LHIST_BINS = 512;          // LDS histogram bins fused into set-ops
 
 enum KhSetOp : int {

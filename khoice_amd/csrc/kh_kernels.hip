@@ -1090,39 +1090,47 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
     const u64 per = (u64)nranges + 1;
     KH_STAMP(q, 0);
 
-    // operand slices of this slot, described in LDS while gathering (lhist is free until then):
-    //   soff[g] u32  (words   0.. 63) first gathered index of operand g's slice (exclusive scan)
-    //   suni[g] u32  (words  64..127) uniform counter of operand g
-    //   sbeg[g] u64  (words 128..255) first element of the slice inside operand g
-    //   skey[g] u64  (words 256..383) operand g's key array
-    //   scnt[g] u64  (words 384..511) operand g's counter array (0 = uniform)
-    u32* soff = lhist;
-    u32* suni = lhist + 64;
-    u64* sbeg = reinterpret_cast<u64*>(lhist + 128);
-    u64* skey = reinterpret_cast<u64*>(lhist + 256);
-    u64* scnt = reinterpret_cast<u64*>(lhist + 384);
-    if (tid < KH_WAVE) {   // nsets <= 64: one wave scans the slice lengths
-        u64 len = 0;
-        if (tid < nsets) {
-            const u64 b0 = bounds[tid * per + q], b1 = bounds[tid * per + q + 1];
-            const KhSetView sv = sets[tid];
-            sbeg[tid] = b0;
-            skey[tid] = reinterpret_cast<u64>(sv.keys);
-            scnt[tid] = reinterpret_cast<u64>(sv.counts);
-            suni[tid] = sv.uniform;
-            len = b1 - b0;
-        }
-        u64 incl = len;
+    // operand slices of this slot, described in LDS while gathering:
+    //   soff[g] u32  first gathered index of operand g's slice (exclusive scan)
+    //   suni[g] u32  uniform counter of operand g
+    //   sbeg[g] u64  first element of the slice inside operand g
+    //   skey[g] u64  operand g's key array
+    //   scnt[g] u64  operand g's counter array (0 = uniform)
+    // (they borrow the head of the key array, which is not written before the gather is over)
+    constexpr u32 MAXG = KH_MAX_INPUT_SETS;
+    u32* dsc = reinterpret_cast<u32*>(s);
+    u32* soff = dsc;
+    u32* suni = dsc + MAXG;
+    u64* sbeg = reinterpret_cast<u64*>(dsc + 2 * MAXG);
+    u64* skey = reinterpret_cast<u64*>(dsc + 4 * MAXG);
+    u64* scnt = reinterpret_cast<u64*>(dsc + 6 * MAXG);
+    if (tid < KH_WAVE) {   // one wave scans the slice lengths, 64 operands per round
+        u64 carry = 0;
+        for (u32 g0 = 0; g0 < nsets; g0 += KH_WAVE) {
+            const u32 g = g0 + tid;
+            u64 len = 0;
+            if (g < nsets) {
+                const u64 b0 = bounds[g * per + q], b1 = bounds[g * per + q + 1];
+                const KhSetView sv = sets[g];
+                sbeg[g] = b0;
+                skey[g] = reinterpret_cast<u64>(sv.keys);
+                scnt[g] = reinterpret_cast<u64>(sv.counts);
+                suni[g] = sv.uniform;
+                len = b1 - b0;
+            }
+            u64 incl = len;
 #pragma unroll
-        for (int off = 1; off < KH_WAVE; off <<= 1) {
-            const u64 u = __shfl_up(incl, off);
-            if (lane >= (u32)off) incl += u;
+            for (int off = 1; off < KH_WAVE; off <<= 1) {
+                const u64 u = __shfl_up(incl, off);
+                if (lane >= (u32)off) incl += u;
+            }
+            if (g < nsets) {
+                const u64 ex = carry + incl - len;
+                soff[g] = ex > 0xffffffffull ? 0xffffffffu : (u32)ex;
+            }
+            carry += __shfl(incl, KH_WAVE - 1);
         }
-        if (tid < nsets) {
-            const u64 ex = incl - len;
-            soff[tid] = ex > 0xffffffffull ? 0xffffffffu : (u32)ex;
-        }
-        if (tid == KH_WAVE - 1) bcast[1] = incl;
+        if (tid == 0) bcast[1] = carry;
     }
     __syncthreads();
     const u64 n64 = bcast[1];

@@ -162,7 +162,7 @@ def test_union_fan_in_above_one_launch(eng):
     k = 15
     base = random_dna(rng, 3000)
     dbs, sets = [], []
-    for g in range(70):
+    for g in range(150):
         s = list(base)
         for _ in range(30):
             s[rng.randrange(len(s))] = rng.choice("ACGT")
