@@ -194,6 +194,7 @@ def main():
                               "frac": round(k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k1_ms else 0.0,
                               "unit": "GB/s"},
         "kernel_ms_per_step": kernel_ms,
+        "replans": st["retries"],
         "setup_seconds": round(gen_s, 1),
     }
 

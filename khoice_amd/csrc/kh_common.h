@@ -125,17 +125,23 @@ constexpr int KH_SUBTILE = 8192;            // k-mer start positions per sub-til
 constexpr int KH_SUBTILES_PER_TILE = 8;     // one workgroup walks 8 sub-tiles = 65536 positions
 constexpr int KH_TILE = KH_SUBTILE * KH_SUBTILES_PER_TILE;
 constexpr int KH_MAX_BUCKETS_PER_SEG = 16384;   // LDS cursor array limit (64 KiB)
-constexpr int KH_BUCKET_MEAN_W1 = 3400;     // target keys per bucket (typical P = 4096)
-constexpr int KH_BUCKET_MEAN_W2 = 1700;
+#ifndef KH_TUNE_MEAN_W1
+#define KH_TUNE_MEAN_W1 3700
+#endif
+#ifndef KH_TUNE_FINE_BITS
+#define KH_TUNE_FINE_BITS 13
+#endif
+constexpr int KH_BUCKET_MEAN_W1 = KH_TUNE_MEAN_W1;     // target keys per bucket (typical P = 4096)
+constexpr int KH_BUCKET_MEAN_W2 = 1850;
 // LDS sort capacity in keys.  Mixed keys make slot sizes Poisson-tight (mean 3400 -> sigma 58),
-// so 4096 leaves 12 sigma; 8 keys per thread keep the unrolled per-thread arrays in <128 VGPRs.
+// so 4096 leaves 6.5 sigma over the 3700 mean (beyond: the oversize path / a re-plan); 8 keys per thread keep the unrolled per-thread arrays in <128 VGPRs.
 constexpr int KH_SORT_CAP_W1 = 4096;
 constexpr int KH_SORT_CAP_W2 = 2048;
 constexpr int KH_SORT_CAP_PAY_W1 = 4096;    // capacity with a 32-bit payload per key
 constexpr int KH_SORT_CAP_PAY_W2 = 2048;
 constexpr int KH_SORT_THREADS = 512;
 constexpr int KH_SORT_WAVES_PER_SIMD = 4;   // 2 workgroups of 8 waves per CU (3 per CU measured slower: spills)
-constexpr int KH_FINE_BITS = 13;            // fine bins of the in-LDS distribution sort
+constexpr int KH_FINE_BITS = KH_TUNE_FINE_BITS;            // fine bins of the in-LDS distribution sort
 constexpr int KH_FINE_BINS = 1 << KH_FINE_BITS;
 constexpr int KH_FINE_LIMIT = 64;           // fullest fine bin the in-bin repair accepts
 constexpr int KH_WORKLIST = 1024;           // keys of out-of-order bins repaired per slot

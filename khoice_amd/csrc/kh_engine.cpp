@@ -471,14 +471,9 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     return KH_OK;
 }
 
-extern "C" int kh_build_batch(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
-                              int on_device, int k, uint32_t ci, uint32_t cx, uint32_t cs,
-                              int with_counts, kh_set** out_sets) {
-    if (!c || !seqs || !lens || !out_sets || nseq <= 0) return kh_fail(KH_E_ARG, "kh_build_batch: bad argument");
-    KHCHK(check_k(k));
-    if (ci < 1) ci = 1;
-    if (cs < 1) return kh_fail(KH_E_ARG, "cs must be >= 1");
-    HIPCHK(hipSetDevice(c->dev));
+static int build_batch_plain(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
+                             int on_device, int k, u32 ci, u32 cx, u32 cs, int with_counts,
+                             kh_set** out_sets) {
     u32 mean = k <= 32 ? KH_BUCKET_MEAN_W1 : KH_BUCKET_MEAN_W2;
     for (int attempt = 0; attempt < 5; ++attempt) {
         bool cap = false;
@@ -490,6 +485,63 @@ extern "C" int kh_build_batch(kh_ctx* c, int nseq, const uint8_t* const* seqs, c
         mean = std::max<u32>(64, mean / 4);
     }
     return kh_fail(KH_E_CAPACITY, "a bucket still holds more distinct k-mers than fit in LDS after 5 re-plans");
+}
+
+extern "C" int kh_build_batch(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
+                              int on_device, int k, uint32_t ci, uint32_t cx, uint32_t cs,
+                              int with_counts, kh_set** out_sets) {
+    if (!c || !seqs || !lens || !out_sets || nseq <= 0) return kh_fail(KH_E_ARG, "kh_build_batch: bad argument");
+    KHCHK(check_k(k));
+    if (ci < 1) ci = 1;
+    if (cs < 1) return kh_fail(KH_E_ARG, "cs must be >= 1");
+    HIPCHK(hipSetDevice(c->dev));
+    // A sequence whose k-mer positions exceed what one segment's bucket table covers (the cursor
+    // table of pass A/B lives in LDS) is cut into chunks that overlap by k-1 bases: every k-mer
+    // start position belongs to exactly one chunk, so the chunk databases add up exactly.
+    const u32 mean = k <= 32 ? KH_BUCKET_MEAN_W1 : KH_BUCKET_MEAN_W2;
+    u64 chunk_pos = (u64)(KH_MAX_BUCKETS_PER_SEG / 4) * mean;
+    if (const char* e = getenv("KHOICE_MAX_SEG_POS")) chunk_pos = std::max<u64>(64, strtoull(e, nullptr, 10));
+    bool any_long = false;
+    for (int i = 0; i < nseq; ++i)
+        if (lens[i] >= (u64)k && lens[i] - k + 1 > chunk_pos) any_long = true;
+    if (!any_long) return build_batch_plain(c, nseq, seqs, lens, on_device, k, ci, cx, cs, with_counts, out_sets);
+    if (ci > 1 || cx != KH_NO_MAX)
+        return kh_fail(KH_E_ARG, "-ci/-cx cut-offs are not supported for sequences of more than %llu k-mer positions",
+                       (unsigned long long)chunk_pos);
+    std::vector<const uint8_t*> cseq;
+    std::vector<uint64_t> clen;
+    std::vector<int> first(nseq + 1, 0);
+    for (int i = 0; i < nseq; ++i) {
+        first[i] = (int)cseq.size();
+        const u64 npos = lens[i] >= (u64)k ? lens[i] - k + 1 : 0;
+        if (npos <= chunk_pos) { cseq.push_back(seqs[i]); clen.push_back(lens[i]); continue; }
+        for (u64 p = 0; p < npos; p += chunk_pos) {
+            const u64 np = std::min(chunk_pos, npos - p);
+            cseq.push_back(seqs[i] + p);
+            clen.push_back(np + k - 1);
+        }
+    }
+    first[nseq] = (int)cseq.size();
+    std::vector<kh_set*> csets(cseq.size(), nullptr);
+    auto cleanup = [&]() { for (auto* s : csets) kh_set_free(s); };
+    // chunk databases keep exact counters (no saturation) until they are added up
+    int r = build_batch_plain(c, (int)cseq.size(), cseq.data(), clen.data(), on_device, k, 1, KH_NO_MAX,
+                              with_counts ? 0x7fffffffu : cs, with_counts, csets.data());
+    if (r != KH_OK) { cleanup(); return r; }
+    for (int i = 0; i < nseq; ++i) out_sets[i] = nullptr;
+    for (int i = 0; i < nseq && r == KH_OK; ++i) {
+        const int m = first[i + 1] - first[i];
+        if (m == 1) { out_sets[i] = csets[first[i]]; csets[first[i]] = nullptr; continue; }
+        kh_set* u = nullptr;
+        r = kh_union_sum(c, csets.data() + first[i], m, with_counts ? cs : 0x7fffffffu, &u, nullptr, 0);
+        if (r != KH_OK) break;
+        if (with_counts) { out_sets[i] = u; continue; }
+        r = kh_set_counts(c, u, 1, &out_sets[i]);     // plain set: every counter 1
+        kh_set_free(u);
+    }
+    if (r != KH_OK) for (int i = 0; i < nseq; ++i) { kh_set_free(out_sets[i]); out_sets[i] = nullptr; }
+    cleanup();
+    return r;
 }
 
 // ------------------------------------------------------------------------------ set ops
@@ -548,7 +600,9 @@ static int setop_prepare(SetopJob& j) {
     j.empty = j.total == 0;
     if (j.empty) return KH_OK;
     j.cap = j.W == 1 ? (j.pay ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_W1) : (j.pay ? KH_SORT_CAP_PAY_W2 : KH_SORT_CAP_W2);
-    j.target = (u64)j.cap * 83 / 100;   // slots are Poisson-tight: mean fill 83 % of LDS capacity
+    // mean fill 83 % of LDS capacity: a union of G sets holds up to G copies of a key, which
+    // widens the slot-size spread to sqrt(G) Poisson sigmas (90 % was measured to re-plan)
+    j.target = (u64)j.cap * 83 / 100;
     JOB_ALLOC(okeys, 8 * (size_t)j.W * j.total);
     JOB_ALLOC(ocnt, 4 * j.total);
     JOB_ALLOC(d_views, sizeof(KhSetView) * nsets);

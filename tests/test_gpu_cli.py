@@ -189,3 +189,35 @@ def test_resident_server_serves_the_same_dag(tmp_path, monkeypatch):
     sh("kmc_tools transform step_3/k_21/dataset_1/dataset_1.transformed.combined histogram again.txt", root2)
     assert open(os.path.join(root2, "again.txt")).read() == \
         open(os.path.join(root2, "step_4/k_21/dataset_1/dataset_1_k21_hist.txt")).read()
+
+
+def test_cli_extras_filelist_cs_and_complex_operators(tmp_path):
+    """Forms beyond khoice's seven: @file lists, -cs, `simple ... union`, `complex` with * and -."""
+    root = str(tmp_path)
+    k = 15
+    recs = [synth.genome_records(3, g, 12_000) for g in range(3)]
+    for i, r in enumerate(recs):
+        open(os.path.join(root, f"g{i}.fa"), "wb").write(synth.fasta_bytes(r))
+    os.makedirs(os.path.join(root, "tmp"))
+    open(os.path.join(root, "list.txt"), "w").write("g0.fa\ng1.fa\n")
+    sh(f"kmc -fm -k{k} -ci1 -cs3 @list.txt both tmp/", root)
+    for i in range(3):
+        sh(f"kmc -fm -k{k} -ci1 g{i}.fa s{i} tmp/", root)
+    dbs = [O.build(synth.fasta_bytes(r), k) for r in recs]
+    both = O.build(synth.fasta_bytes(recs[0]) + synth.fasta_bytes(recs[1]), k, cs=3)
+    sh("kmc_tools transform both dump -s both.txt", root)
+    assert open(os.path.join(root, "both.txt")).read() == O.dump_sorted_text(both, k)
+    sh("kmc_tools simple s0 s1 union u01 -ocmax -cs7", root)
+    sh("kmc_tools transform u01 dump -s u01.txt", root)
+    assert open(os.path.join(root, "u01.txt")).read() == O.dump_sorted_text(O.union2(dbs[0], dbs[1], "max", cs=7), k)
+    open(os.path.join(root, "ops.txt"), "w").write(
+        "INPUT:\na = s0\nb = s1\nc = s2\nOUTPUT:\nres = (a * b) - c\nOUTPUT_PARAMS:\n-cs200\n")
+    sh("kmc_tools complex ops.txt", root)
+    sh("kmc_tools transform res dump -s res.txt", root)
+    want = O.kmers_subtract(O.intersect(dbs[0], dbs[1], "min", cs=1 << 30), dbs[2])
+    want = {c: min(n, 200) for c, n in want.items()}
+    assert open(os.path.join(root, "res.txt")).read() == O.dump_sorted_text(want, k)
+    # default -ci2 of kmc (khoice always passes -ci1): singletons are dropped
+    sh(f"kmc -fm -k{k} g0.fa d2 tmp/", root)
+    sh("kmc_tools transform d2 dump -s d2.txt", root)
+    assert open(os.path.join(root, "d2.txt")).read() == O.dump_sorted_text(O.build(synth.fasta_bytes(recs[0]), k, ci=2), k)

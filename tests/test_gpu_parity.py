@@ -351,3 +351,24 @@ def test_exp1_group_waves_equal_single_wave(eng, monkeypatch):
         assert (got["within_hist"] == want["within_hist"]).all()
         assert (got["across_hist"] == want["across_hist"]).all()
         assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+
+
+def test_long_sequences_are_chunked(eng, monkeypatch):
+    """Sequences beyond one segment's bucket table are cut into overlapping chunks whose
+    databases add up exactly (forced here by a tiny segment limit)."""
+    rng = random.Random(99)
+    seqs = [random_dna(rng, n, "ACGTN" if i else "ACGT").encode() for i, n in enumerate((50_000, 9_000, 31_000))]
+    for k in (21, 41):
+        want = [O.count_records(s.decode().split("\n"), k, cs=1 << 30) for s in seqs]
+        monkeypatch.setenv("KHOICE_MAX_SEG_POS", "7000")
+        got = eng.build_batch(seqs, k, cs=1 << 30)
+        plain = eng.build_batch(seqs, k, with_counts=False)
+        monkeypatch.delenv("KHOICE_MAX_SEG_POS")
+        for w, g, p in zip(want, got, plain):
+            assert set_to_db(g) == w
+            assert set_to_db(p) == O.set_counts(w, 1)
+        # default saturation applies after the chunks are added up
+        monkeypatch.setenv("KHOICE_MAX_SEG_POS", "7000")
+        sat = eng.build((b"A" * 30_000), k)
+        monkeypatch.delenv("KHOICE_MAX_SEG_POS")
+        assert set_to_db(sat) == {0: 255}
