@@ -152,6 +152,9 @@ int kh_set_from_device(kh_ctx *ctx, int k, uint64_t n, const void *keys_mixed,
 /* index of the first key of every one of `nparts` equal-width slots of the mixed key
  * space: bounds[nparts+1] (host).  Used to slice a set for the all-to-all exchange. */
 int kh_set_partition_bounds(kh_ctx *ctx, const kh_set *set, uint32_t nparts, uint64_t *bounds);
+/* the same for nsets sets in one launch: bounds[nsets][nparts+1] */
+int kh_sets_partition_bounds(kh_ctx *ctx, const kh_set *const *sets, int nsets, uint32_t nparts,
+                             uint64_t *bounds);
 
 /* ---------------------------------------------------------------- database files
  * `<prefix>.kmc_pre` + `<prefix>.kmc_suf` (names required by the Snakemake rules,

@@ -37,17 +37,12 @@ KH_HD bool key_lt(const KmerKey<2>& a, const KmerKey<2>& b) {
     return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo);
 }
 KH_HD bool key_eq(const KmerKey<2>& a, const KmerKey<2>& b) { return a.hi == b.hi && a.lo == b.lo; }
-KH_HD void key_set_max(KmerKey<1>& a) { a.lo = ~0ull; }
-KH_HD void key_set_max(KmerKey<2>& a) { a.lo = ~0ull; a.hi = ~0ull; }
 
 KH_HD u64 kh_mask(int nbits) { return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull); }
 
 // ---------------------------------------------------------------- bijective mixing
 constexpr u64 KH_C1 = 0xff51afd7ed558ccdull;   // odd multipliers (murmur3 / splitmix family)
-constexpr u64 KH_C2 = 0xc4ceb9fe1a85ec53ull;
 constexpr u64 KH_C3 = 0x9e3779b97f4a7c15ull;
-constexpr u64 KH_C4 = 0xbf58476d1ce4e5b9ull;
-constexpr u64 KH_C5 = 0x94d049bb133111ebull;
 
 constexpr u64 kh_modinv(u64 c) {   // inverse of odd c modulo 2^64 (Newton)
     u64 x = c;
@@ -55,8 +50,7 @@ constexpr u64 kh_modinv(u64 c) {   // inverse of odd c modulo 2^64 (Newton)
     return x;
 }
 constexpr u64 KH_C1_INV = kh_modinv(KH_C1);
-constexpr u64 KH_C2_INV = kh_modinv(KH_C2);
-static_assert(KH_C1 * KH_C1_INV == 1ull && KH_C2 * KH_C2_INV == 1ull, "modinv");
+static_assert(KH_C1 * KH_C1_INV == 1ull, "modinv");
 
 // bijection on [0, 2^n), 2 <= n <= 64.  s >= n/2 so one xor-shift step is its own inverse.
 // One odd multiply between two folds: the fold brings the high half into the low bits, the

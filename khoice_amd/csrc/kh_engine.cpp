@@ -905,6 +905,27 @@ extern "C" int kh_set_partition_bounds(kh_ctx* c, const kh_set* s, uint32_t npar
     return KH_OK;
 }
 
+extern "C" int kh_sets_partition_bounds(kh_ctx* c, const kh_set* const* sets, int nsets, uint32_t nparts,
+                                        uint64_t* bounds) {
+    if (!c || !sets || !bounds || !nparts || nsets <= 0) return kh_fail(KH_E_ARG, "kh_sets_partition_bounds: bad argument");
+    HIPCHK(hipSetDevice(c->dev));
+    const int k = sets[0]->k, W = sets[0]->W;
+    std::vector<KhSetView> v(nsets);
+    for (int i = 0; i < nsets; ++i) {
+        if (!sets[i] || sets[i]->k != k) return kh_fail(KH_E_KMISMATCH, "sets built with different k");
+        v[i] = KhSetView{sets[i]->n ? sets[i]->keys_ptr() : nullptr, nullptr, sets[i]->n, 1, 0};
+    }
+    Tmp d_view, d_bounds;
+    const u64 nb = ((u64)nparts + 1) * nsets;
+    TMP_ALLOC(d_view, c, sizeof(KhSetView) * nsets);
+    TMP_ALLOC(d_bounds, c, 8 * nb);
+    HIPCHK(hipMemcpyAsync(d_view.b->p, v.data(), sizeof(KhSetView) * nsets, hipMemcpyHostToDevice, c->st));
+    kh_launch_range_bounds(W, d_view.as<KhSetView>(), nsets, nparts, k, d_bounds.as<u64>(), c->st);
+    HIPCHK(hipMemcpyAsync(bounds, d_bounds.b->p, 8 * nb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return KH_OK;
+}
+
 // ------------------------------------------------------------------------------ fused exp 1
 extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
                            int on_device, const int* group_of, int ngroups, int k, uint32_t cs,

@@ -75,46 +75,6 @@ __device__ __forceinline__ u64 lb_load(u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Called by the 64 lanes of wave 0.  Publishes `mine`, returns the exclusive prefix.
-__device__ u64 lookback_wave(u64* desc, u32 q, u64 mine, u32* err) {
-    const u32 lane = lane_id();
-    if (q == 0) {
-        if (lane == 0) lb_store(&desc[0], KH_LB_PREFIX | mine);
-        return 0;
-    }
-    if (lane == 0) lb_store(&desc[q], KH_LB_AGG | mine);
-    u64 excl = 0;
-    long long base = (long long)q - 1;
-    bool timed_out = false;
-    while (true) {
-        const long long idx = base - (long long)lane;
-        u64 d = KH_LB_PREFIX;   // "before the first part": prefix 0
-        if (idx >= 0) {
-            d = lb_load(&desc[idx]);
-            u32 spins = 0;
-            while ((d >> 62) == 0) {
-                __builtin_amdgcn_s_sleep(2);
-                d = lb_load(&desc[idx]);
-                if (++spins > (1u << 22)) { timed_out = true; d = KH_LB_PREFIX; break; }
-            }
-        }
-        const u64 is_prefix = __ballot((d >> 62) == 2);
-        u64 v = d & KH_LB_VALUE;
-        if (is_prefix) {
-            const u32 first = (u32)__ffsll((unsigned long long)is_prefix) - 1u;
-            v = (lane <= first) ? v : 0ull;
-        }
-        // wave sum of v
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        excl += v;
-        if (is_prefix) break;
-        base -= KH_WAVE;
-    }
-    if (__ballot(timed_out) && lane == 0) atomicOr(err, KH_ERR_SPIN_TIMEOUT);
-    if (lane == 0) lb_store(&desc[q], KH_LB_PREFIX | ((excl + mine) & KH_LB_VALUE));
-    return excl;
-}
-
 // ------------------------------------------------------------------------------------------
 // pass A / pass B: base decoding, rolling canonical k-mer, mixing, bucket histogram / scatter
 // ------------------------------------------------------------------------------------------
@@ -590,7 +550,7 @@ __device__ u64 lookback_block(u64* desc, const u32 q, const u64 mine, u32* err, 
             while ((dsc >> 62) == 0) {
                 __builtin_amdgcn_s_sleep(2);
                 dsc = lb_load(&desc[idx]);
-                if (++spins > (1u << 22)) { timed_out = true; dsc = KH_LB_PREFIX; break; }
+                if (++spins > (1u << 25)) { timed_out = true; dsc = KH_LB_PREFIX; break; }
             }
         }
         const u64 pm = __ballot((dsc >> 62) == 2);
@@ -1261,14 +1221,6 @@ __global__ void k_fill_u32(u32* __restrict__ p, u64 n, u32 v) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
-__global__ void k_clamp_u32(const u32* __restrict__ in, u32* __restrict__ out, u64 n, u32 cs) {
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const u32 v = in[i];
-        out[i] = v < cs ? v : cs;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -1395,22 +1347,7 @@ void kh_launch_unmix(int W, const void* in, void* out, u64 n, int k, hipStream_t
                            reinterpret_cast<const KmerKey<2>*>(in),
                            reinterpret_cast<KmerKey<2>*>(out), n, k);
 }
-void kh_launch_mix(int W, const void* in, void* out, u64 n, int k, hipStream_t st) {
-    if (!n) return;
-    if (W == 1)
-        hipLaunchKernelGGL((k_remix<1, false>), dim3(grid_for(n, 256)), dim3(256), 0, st,
-                           reinterpret_cast<const KmerKey<1>*>(in),
-                           reinterpret_cast<KmerKey<1>*>(out), n, k);
-    else
-        hipLaunchKernelGGL((k_remix<2, false>), dim3(grid_for(n, 256)), dim3(256), 0, st,
-                           reinterpret_cast<const KmerKey<2>*>(in),
-                           reinterpret_cast<KmerKey<2>*>(out), n, k);
-}
 void kh_launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n, 256)), dim3(256), 0, st, p, n, v);
-}
-void kh_launch_clamp_u32(const u32* in, u32* out, u64 n, u32 cs, hipStream_t st) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_clamp_u32, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, n, cs);
 }

@@ -54,6 +54,4 @@ void kh_launch_setop(int W, bool pay, u32 cap, const KhSetView* sets, u32 nsets,
 void kh_launch_histogram(const u32* counts, u64 n, unsigned long long* hist, u32 hist_len,
                          hipStream_t st);
 void kh_launch_unmix(int W, const void* in, void* out, u64 n, int k, hipStream_t st);
-void kh_launch_mix(int W, const void* in, void* out, u64 n, int k, hipStream_t st);
 void kh_launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st);
-void kh_launch_clamp_u32(const u32* in, u32* out, u64 n, u32 cs, hipStream_t st);

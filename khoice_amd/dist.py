@@ -56,6 +56,9 @@ class EngineOps:
     def partition_bounds(self, s, nparts):
         return s.partition_bounds(nparts)
 
+    def partition_bounds_all(self, sets, nparts):
+        return self.eng.partition_bounds(sets, nparts)
+
     def export_range(self, s, lo, hi, keys_t, counts_t):
         s.export_range(lo, hi, keys_t.data_ptr(), counts_t.data_ptr() if counts_t is not None else None)
 
@@ -84,7 +87,11 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
     w = ops.words(k)
     g_local = len(group_sets)
     # slot boundaries of every local group set: bounds[g][j] .. bounds[g][j+1] goes to rank j
-    bounds = [np.asarray(ops.partition_bounds(s, world), dtype=np.int64) for s in group_sets]
+    if hasattr(ops, "partition_bounds_all"):     # one launch + one synchronisation for all sets
+        ball = np.asarray(ops.partition_bounds_all(list(group_sets), world), dtype=np.int64)
+        bounds = [ball[g] for g in range(g_local)]
+    else:
+        bounds = [np.asarray(ops.partition_bounds(s, world), dtype=np.int64) for s in group_sets]
     meta = torch.tensor([g_local, int(any(ops.has_counts(s) for s in group_sets))], dtype=torch.int64, device=cdev)
     metas = [torch.empty_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)

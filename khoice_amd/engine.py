@@ -78,6 +78,7 @@ def load_library(path: Optional[str] = None):
         "kh_set_export_range": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, vp]),
         "kh_set_wrap_device": (C.c_int, [vp, C.c_int, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(vp)]),
         "kh_set_partition_bounds": (C.c_int, [vp, vp, C.c_uint32, u64p]),
+        "kh_sets_partition_bounds": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_uint32, u64p]),
         "kh_save": (C.c_int, [vp, vp, C.c_char_p]),
         "kh_load": (C.c_int, [vp, C.c_char_p, C.POINTER(vp)]),
         "kh_exp1_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), u64p, C.c_int, C.POINTER(C.c_int), C.c_int,
@@ -103,6 +104,7 @@ ABI_SYMBOLS = [
     "kh_set_download",
     "kh_set_upload", "kh_set_device_ptrs", "kh_set_from_device", "kh_set_export_device",
     "kh_set_export_range", "kh_set_wrap_device", "kh_set_partition_bounds",
+    "kh_sets_partition_bounds",
     "kh_save", "kh_load", "kh_exp1_run", "kh_mix_host", "kh_unmix_host",
 ]
 
@@ -348,6 +350,15 @@ class Engine:
         out = C.c_void_p()
         _check(self._lib.kh_set_from_device(self._ctx, k, n, keys_ptr, counts_ptr, C.byref(out)))
         return KmerSet(self, out.value)
+
+    def partition_bounds(self, sets: Sequence[KmerSet], nparts: int) -> np.ndarray:
+        """bounds[len(sets), nparts + 1] of several sets with one launch and one synchronisation."""
+        n = len(sets)
+        out = np.zeros((n, nparts + 1), dtype=np.uint64)
+        if n:
+            arr = (C.c_void_p * n)(*[s._h for s in sets])
+            _check(self._lib.kh_sets_partition_bounds(self._ctx, arr, n, nparts, _u64p(out)))
+        return out
 
     def wrap_device(self, k: int, n: int, keys_ptr: int, counts_ptr: Optional[int] = None,
                     uniform: int = 1) -> KmerSet:
