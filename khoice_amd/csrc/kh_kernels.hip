@@ -394,32 +394,36 @@ __global__ void k_col_offsets(const KhSeg* __restrict__ segs, u32* __restrict__ 
     }
 }
 
-// exclusive scan of n u64 values by one 1024-thread block; out[n] = total.
+// exclusive scan of n u64 values by one 1024-thread block; out[n] = total.  Tiles of 1024
+// consecutive elements (coalesced), wave shuffles inside a tile, a running carry across tiles.
 __global__ __launch_bounds__(1024) void k_exscan(const u64* __restrict__ in, u64* __restrict__ out,
                                                  u64 n) {
-    __shared__ u64 part[1024];
-    const u32 tid = threadIdx.x;
-    const u64 chunk = (n + 1023) / 1024;
-    const u64 lo = (u64)tid * chunk;
-    const u64 hi = lo + chunk < n ? lo + chunk : n;
-    u64 s = 0;
-    for (u64 i = lo; i < hi; ++i) s += in[i];
-    part[tid] = s;
-    __syncthreads();
-    for (u32 off = 1; off < 1024; off <<= 1) {
-        u64 v = 0;
-        if (tid >= off) v = part[tid - off];
+    __shared__ u64 wsum[16];
+    const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    u64 carry = 0;
+    for (u64 base = 0; base < n; base += 1024) {
+        const u64 i = base + tid;
+        const u64 v = i < n ? in[i] : 0ull;
+        u64 incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u64 u = __shfl_up(incl, off);
+            if (lane >= (u32)off) incl += u;
+        }
+        if (lane == 63) wsum[wid] = incl;
         __syncthreads();
-        part[tid] += v;
+        u64 before = 0, total = 0;
+#pragma unroll
+        for (u32 w = 0; w < 16; ++w) {
+            const u64 x = wsum[w];
+            before += w < wid ? x : 0ull;
+            total += x;
+        }
+        if (i < n) out[i] = carry + before + incl - v;
+        carry += total;
         __syncthreads();
     }
-    u64 run = part[tid] - s;   // exclusive prefix of this thread's chunk
-    for (u64 i = lo; i < hi; ++i) {
-        const u64 v = in[i];
-        out[i] = run;
-        run += v;
-    }
-    if (tid == 1023) out[n] = part[1023];
+    if (tid == 0) out[n] = carry;
 }
 
 // ------------------------------------------------------------------------------------------
