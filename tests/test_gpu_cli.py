@@ -221,3 +221,41 @@ def test_cli_extras_filelist_cs_and_complex_operators(tmp_path):
     sh(f"kmc -fm -k{k} g0.fa d2 tmp/", root)
     sh("kmc_tools transform d2 dump -s d2.txt", root)
     assert open(os.path.join(root, "d2.txt")).read() == O.dump_sorted_text(O.build(synth.fasta_bytes(recs[0]), k, ci=2), k)
+
+
+def test_concurrent_processes_share_the_gpu(tmp_path):
+    """`snakemake --cores N` runs N rule processes at once: independent contexts on one GPU, and
+    concurrent clients of one server, must all produce the same databases as serial runs."""
+    import time
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "tmp"))
+    names = []
+    for g in range(4):    # the GPU box admits 6 processes on the card; pytest itself is one
+        name = f"g{g}"
+        open(os.path.join(root, name + ".fa"), "wb").write(synth.fasta_bytes(synth.genome_records(5, g, 150_000)))
+        names.append(name)
+    jobs = " & ".join(f"kmc -fm -m64 -k31 -ci1 {n}.fa par_{n} tmp/ > /dev/null" for n in names)
+    sh(f"{jobs} & wait", root)
+    for n in names:
+        sh(f"kmc -fm -m64 -k31 -ci1 {n}.fa ser_{n} tmp/ > /dev/null", root)
+        for ext in (".kmc_pre", ".kmc_suf"):
+            assert open(os.path.join(root, f"par_{n}{ext}"), "rb").read() == \
+                open(os.path.join(root, f"ser_{n}{ext}"), "rb").read(), n
+    sock = os.path.join(root, "s.sock")
+    srv = subprocess.Popen([os.path.join(BIN, "khoice_server"), sock], stderr=subprocess.DEVNULL)
+    try:
+        for _ in range(200):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        jobs = " & ".join(f"KHOICE_SERVER={sock} kmc_tools transform ser_{n} set_counts 1 set_{n}" for n in names)
+        sh(f"{jobs} & wait", root)
+        ops = "INPUT:\n" + "".join(f"set{i + 1} = set_{n}\n" for i, n in enumerate(names)) + \
+              "OUTPUT:\nunion = (" + " + ".join(f"set{i + 1}" for i in range(len(names))) + " )\nOUTPUT_PARAMS:\n-cs5000\n"
+        open(os.path.join(root, "ops.txt"), "w").write(ops)
+        sh(f"KHOICE_SERVER={sock} kmc_tools complex ops.txt && KHOICE_SERVER={sock} kmc_tools transform union histogram h.txt", root)
+    finally:
+        subprocess.run([os.path.join(BIN, "khoice_server"), "--stop", sock], timeout=30)
+        srv.wait(timeout=30)
+    dbs = [O.set_counts(O.build(open(os.path.join(root, n + ".fa"), "rb").read(), 31), 1) for n in names]
+    assert open(os.path.join(root, "h.txt")).read() == O.histogram_text(O.union_sum(dbs, 5000), 65535)
