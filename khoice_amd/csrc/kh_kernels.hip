@@ -620,16 +620,24 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
     constexpr u32 WORDS = KH_FINE_BINS / 2;
     constexpr u32 PER = WORDS / NT;   // packed words scanned per thread
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    // Every phase below is written as "issue all LDS operations of the thread, then consume":
+    // used inside one predicated block, a result makes hipcc wait (lgkmcnt(0)) before the next
+    // block, which chains the E LDS latencies of a thread instead of overlapping them.
     u32 fr[E];   // fine bin << 16 | arrival rank inside the bin
+    u32 vmask = 0;   // bit e: element e*NT + tid exists
+    {
+        u32 old[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        fr[e] = 0;
-        if ((u32)e * NT + tid < n) {
-            const u32 f = fine_bin<W>(kreg[e], k, nslots);
-            const u32 sh = 16 * (f & 1);
-            const u32 old = atomicAdd(&bins[f >> 1], 1u << sh);
-            fr[e] = (f << 16) | ((old >> sh) & 0xffffu);
+        for (int e = 0; e < E; ++e) {
+            fr[e] = fine_bin<W>(kreg[e], k, nslots);
+            old[e] = 0;
+            if ((u32)e * NT + tid < n) {
+                vmask |= 1u << e;
+                old[e] = atomicAdd(&bins[fr[e] >> 1], 1u << (16 * (fr[e] & 1)));
+            }
         }
+#pragma unroll
+        for (int e = 0; e < E; ++e) fr[e] = (fr[e] << 16) | ((old[e] >> (16 * (fr[e] & 1))) & 0xffffu);
     }
     __syncthreads();
     KH_STAMP(q, 2);
@@ -673,12 +681,14 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
     if (tid == NT - 1) bins[WORDS] = run;   // base of the bin past the last one = n
     __syncthreads();
     KH_STAMP(q, 3);
+    u32 at[E];   // position after the scatter
+#pragma unroll
+    for (int e = 0; e < E; ++e) at[e] = bin_base(bins, fr[e] >> 16) + (fr[e] & 0xffffu);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        if ((u32)e * NT + tid < n) {
-            const u32 at = bin_base(bins, fr[e] >> 16) + (fr[e] & 0xffffu);
-            s[at] = kreg[e];
-            if (PAY) pay[at] = preg[e];
+        if (vmask & (1u << e)) {
+            s[at[e]] = kreg[e];
+            if (PAY) pay[at[e]] = preg[e];
         }
     }
     __syncthreads();
@@ -690,25 +700,31 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
     }
     if (bmax > 1) {
         // (a) a bin is out of order iff some key is smaller than its predecessor in the bin
+        {
+            KmerKey<W> pred[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if ((u32)e * NT + tid < n && (fr[e] & 0xffffu) != 0) {
-                const u32 f = fr[e] >> 16;
-                const u32 at = bin_base(bins, f) + (fr[e] & 0xffffu);
-                if (key_lt(kreg[e], s[at - 1])) atomicOr(&dirty[f >> 5], 1u << (f & 31));
+            for (int e = 0; e < E; ++e) pred[e] = s[at[e] ? at[e] - 1 : 0];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if ((vmask & (1u << e)) && (fr[e] & 0xffffu) != 0 && key_lt(kreg[e], pred[e])) {
+                    const u32 f = fr[e] >> 16;
+                    atomicOr(&dirty[f >> 5], 1u << (f & 31));
+                }
             }
         }
         __syncthreads();
         // (b) keys of out-of-order bins (a few per cent of all keys) enter a work list, so that
         // the repair below runs with dense lanes instead of diverging over all keys
+        {
+            u32 dw[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if ((u32)e * NT + tid < n) {
+            for (int e = 0; e < E; ++e) dw[e] = dirty[fr[e] >> 21];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
                 const u32 f = fr[e] >> 16;
-                if ((dirty[f >> 5] >> (f & 31)) & 1u) {
-                    const u32 at = bin_base(bins, f) + (fr[e] & 0xffffu);
+                if ((vmask & (1u << e)) && ((dw[e] >> (f & 31)) & 1u)) {
                     const u32 w = atomicAdd(&scratch[20], 1u);
-                    if (w < (u32)KH_WORKLIST) wl[w] = at | (f << 12);
+                    if (w < (u32)KH_WORKLIST) wl[w] = at[e] | (f << 12);
                 }
             }
         }
@@ -795,15 +811,25 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
     const u64 lt_mask = (1ull << lane) - 1ull;
     u32 lr[E];
     u32 flags = 0;
-    // ---- (1) run heads
+    // ---- (1) run heads (all LDS reads of the thread are issued before the first is used)
+    KmerKey<W> cur[E];
+    {
+        KmerKey<W> prv[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const u32 i = (u32)e * NT + tid;
-        const bool head = (i < n) && (i == 0 || !key_eq(s[i], s[i - 1]));
-        const u64 bal = __ballot(head);
-        if (lane == 0) tab[e * 8 + wid] = (u32)__popcll(bal);
-        lr[e] = (u32)__popcll(bal & lt_mask);
-        flags |= head ? (1u << e) : 0u;
+        for (int e = 0; e < E; ++e) {
+            const u32 i = (u32)e * NT + tid;
+            cur[e] = s[i < n ? i : 0];
+            prv[e] = s[(i < n && i) ? i - 1 : 0];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const u32 i = (u32)e * NT + tid;
+            const bool head = (i < n) && (i == 0 || !key_eq(cur[e], prv[e]));
+            const u64 bal = __ballot(head);
+            if (lane == 0) tab[e * 8 + wid] = (u32)__popcll(bal);
+            lr[e] = (u32)__popcll(bal & lt_mask);
+            flags |= head ? (1u << e) : 0u;
+        }
     }
     table_scan<E>(tab);
     const u32 d = tab[E * 8];
@@ -819,7 +845,7 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
         const u64 ob = lookback_block(lb.desc, q, (u64)d, lb.err, scratch);
 #pragma unroll
         for (int e = 0; e < E; ++e)
-            if (flags & (1u << e)) sink(ob + base[e], s[(u32)e * NT + tid], 1u);
+            if (flags & (1u << e)) sink(ob + base[e], cur[e], 1u);
         return;
     }
 #pragma unroll
@@ -830,14 +856,20 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
     KH_STAMP(q, 6);
     if (all_kept) {
         // every run is kept: output rank = run index, only the counters remain to be evaluated
+        u32 h0[E], h1[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const u32 r = (u32)e * NT + tid;
+            h0[e] = hstart[r < d ? r : 0];
+            h1[e] = hstart[r < d ? r + 1 : 0];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) cur[e] = s[h0[e]];
         const u64 ob = lookback_block(lb.desc, q, (u64)d, lb.err, scratch);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const u32 r = (u32)e * NT + tid;
-            if (r < d) {
-                const u32 h0 = hstart[r];
-                sink(ob + r, s[h0], eval(h0, (u32)hstart[r + 1]));
-            }
+            if (r < d) sink(ob + r, cur[e], eval(h0[e], h1[e]));
         }
         return;
     }
