@@ -715,18 +715,31 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
         __syncthreads();
         // (b) keys of out-of-order bins (a few per cent of all keys) enter a work list, so that
         // the repair below runs with dense lanes instead of diverging over all keys
+        // (one list-length atomic per wave: the wave's entries are ranked by ballots)
         {
             u32 dw[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) dw[e] = dirty[fr[e] >> 21];
+            const u64 lt_mask = (1ull << lane) - 1ull;
+            u32 listed = 0, rank[E], mine = 0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const u32 f = fr[e] >> 16;
-                if ((vmask & (1u << e)) && ((dw[e] >> (f & 31)) & 1u)) {
-                    const u32 w = atomicAdd(&scratch[20], 1u);
-                    if (w < (u32)KH_WORKLIST) wl[w] = at[e] | (f << 12);
-                }
+                const bool on = (vmask & (1u << e)) && ((dw[e] >> (f & 31)) & 1u);
+                const u64 bal = __ballot(on);
+                rank[e] = listed + (u32)__popcll(bal & lt_mask);
+                listed += (u32)__popcll(bal);
+                mine |= on ? (1u << e) : 0u;
             }
+            u32 base = 0;
+            if (listed) {
+                if (lane == 0) base = atomicAdd(&scratch[20], listed);
+                base = __shfl(base, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((mine & (1u << e)) && base + rank[e] < (u32)KH_WORKLIST)
+                    wl[base + rank[e]] = at[e] | ((fr[e] >> 16) << 12);
         }
         __syncthreads();
         const u32 wlc = scratch[20];
