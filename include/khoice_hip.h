@@ -112,6 +112,16 @@ int kh_simple(kh_ctx *ctx, const kh_set *a, const kh_set *b, int op, int mode, u
  * `kmc_tools transform IN histogram OUT.txt`      exp_type_1.smk:191,259
  * hist[c], c in [0, hist_len); counters >= hist_len are added to the last bin. */
 int kh_histogram(kh_ctx *ctx, const kh_set *set, uint64_t *hist, uint32_t hist_len);
+/* Small-k form of the across-group occurrence count (exp_type_1.smk:243-259 for k <= 16): a
+ * direct-addressed table of 4^k cells in DEVICE memory (cell_bytes 1 or 4, caller-owned, zeroed by
+ * the caller); kh_table_add_set adds 1 (saturating) to the cell of every k-mer of `set`, so after
+ * adding each group set once, cell v = number of groups holding canonical k-mer v.  Tables of
+ * several GPUs are summed by the caller (RCCL all-reduce).  kh_table_histogram:
+ * hist[min(cell, cs, hist_len-1)] += 1 over the non-zero cells of [lo, hi) (cs 0 = no cap);
+ * lo*cell_bytes must be a multiple of 16.  Work is queued on the context's stream. */
+int kh_table_add_set(kh_ctx *ctx, const kh_set *set, void *d_table, uint32_t cell_bytes);
+int kh_table_histogram(kh_ctx *ctx, const void *d_table, uint32_t cell_bytes, uint64_t lo, uint64_t hi,
+                       uint32_t cs, uint64_t *hist, uint32_t hist_len);
 /* text form consumed at exp_type_1.smk:210-212: lines "c<TAB>n", c = 1..cmax */
 int kh_histogram_file(kh_ctx *ctx, const kh_set *set, uint32_t cmax, const char *path);
 

@@ -139,6 +139,7 @@ constexpr int KH_FINE_BITS = KH_TUNE_FINE_BITS;            // fine bins of the i
 constexpr int KH_FINE_BINS = 1 << KH_FINE_BITS;
 constexpr int KH_FINE_LIMIT = 64;           // fullest fine bin the in-bin repair accepts
 constexpr int KH_WORKLIST = 1024;           // keys of out-of-order bins repaired per slot
+constexpr int KH_TABLE_MAX_K = 16;          // direct-addressed occurrence table: 4^16 cells at most
 constexpr int KH_MAX_INPUT_SETS = 128;      // fan-in of one set-operation launch
 constexpr int KH_LHIST_BINS = 512;          // LDS histogram bins fused into set-ops
 

@@ -749,6 +749,43 @@ extern "C" int kh_histogram(kh_ctx* c, const kh_set* s, uint64_t* hist, uint32_t
     return KH_OK;
 }
 
+// ------------------------------------------------------------------- occurrence table
+// Small-k variant of the across-group step: cell v of a 4^k-cell table in
+// device memory counts the sets that hold canonical k-mer v.
+extern "C" int kh_table_add_set(kh_ctx* c, const kh_set* s, void* d_table, uint32_t cell_bytes) {
+    if (!c || !s || !d_table) return kh_fail(KH_E_ARG, "kh_table_add_set: NULL argument");
+    if (cell_bytes != 1 && cell_bytes != 4) return kh_fail(KH_E_ARG, "kh_table_add_set: cell_bytes must be 1 or 4");
+    if (s->k > KH_TABLE_MAX_K) return kh_fail(KH_E_ARG, "kh_table_add_set: k > 16 has no direct-addressed table");
+    HIPCHK(hipSetDevice(c->dev));
+    if (!s->n) return KH_OK;
+    c->prof_begin(KC_HISTOGRAM);
+    kh_launch_table_add(s->keys_ptr(), s->n, s->k, d_table, cell_bytes, c->st);
+    c->prof_end();
+    HIPCHK(hipGetLastError());
+    return KH_OK;
+}
+
+extern "C" int kh_table_histogram(kh_ctx* c, const void* d_table, uint32_t cell_bytes, uint64_t lo,
+                                  uint64_t hi, uint32_t cs, uint64_t* hist, uint32_t hist_len) {
+    if (!c || !d_table || !hist || hist_len < 2) return kh_fail(KH_E_ARG, "kh_table_histogram: bad argument");
+    if (cell_bytes != 1 && cell_bytes != 4) return kh_fail(KH_E_ARG, "kh_table_histogram: cell_bytes must be 1 or 4");
+    if (hi < lo || (lo * cell_bytes) % 16 || ((uintptr_t)d_table % 16))
+        return kh_fail(KH_E_ARG, "kh_table_histogram: the range must start on a 16-byte boundary");
+    HIPCHK(hipSetDevice(c->dev));
+    memset(hist, 0, 8 * (size_t)hist_len);
+    if (hi == lo) return KH_OK;
+    Tmp d_hist;
+    TMP_ALLOC(d_hist, c, 8 * (u64)hist_len);
+    HIPCHK(hipMemsetAsync(d_hist.b->p, 0, 8 * (u64)hist_len, c->st));
+    c->prof_begin(KC_HISTOGRAM);
+    kh_launch_table_hist(d_table, cell_bytes, lo, hi, cs ? cs : 0xFFFFFFFFu, d_hist.as<unsigned long long>(),
+                         hist_len, c->st);
+    c->prof_end();
+    HIPCHK(hipMemcpyAsync(hist, d_hist.b->p, 8 * (size_t)hist_len, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return KH_OK;
+}
+
 // ------------------------------------------------------------------------------ transfer
 extern "C" int kh_set_download(kh_ctx* c, const kh_set* s, uint64_t* keys, uint32_t* counts) {
     if (!c || !s) return kh_fail(KH_E_ARG, "kh_set_download: NULL argument");

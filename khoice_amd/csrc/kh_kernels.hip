@@ -1270,6 +1270,63 @@ __global__ void k_fill_u32(u32* __restrict__ p, u64 n, u32 v) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
+
+// ------------------------------------------------------------------------------------------
+// Direct-addressed occurrence table for small k (k <= 16, 4^k cells).
+// A set holds DISTINCT keys, so one launch touches every cell at most once: a plain byte (or
+// dword) read-modify-write is race-free; different sets are added in stream order.
+// ------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256) void k_table_add(const KmerKey<1>* __restrict__ keys, u64 n, int k,
+                                                  C* __restrict__ table, u32 cmax) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u64 v = kh_unmix(keys[i], k).lo;
+        const u32 c = table[v];
+        if (c < cmax) table[v] = (C)(c + 1);
+    }
+}
+
+// hist[min(c, cs, hist_len-1)] += 1 for every non-zero cell of table[lo, hi); cells are read
+// 16 bytes at a time (lo and hi are multiples of 16 cells except at the very end of the table).
+template <class C>
+__global__ __launch_bounds__(256) void k_table_hist(const C* __restrict__ table, u64 lo, u64 hi, u32 cs,
+                                                   unsigned long long* __restrict__ hist, u32 hist_len) {
+    __shared__ u32 lh[KH_LHIST_BINS];
+    for (u32 i = threadIdx.x; i < KH_LHIST_BINS; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    constexpr u32 PER = 16 / sizeof(C);
+    const u64 nvec = (hi - lo) / PER;
+    const uint4* __restrict__ vp = reinterpret_cast<const uint4*>(table + lo);
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    auto put = [&](u32 c) {
+        if (!c) return;
+        if (c > cs) c = cs;
+        if (c < KH_LHIST_BINS) atomicAdd(&lh[c], 1u);
+        else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
+    };
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const uint4 q = vp[i];
+        const u32 w4[4] = {q.x, q.y, q.z, q.w};
+        if (!(q.x | q.y | q.z | q.w)) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (sizeof(C) == 4) put(w4[j]);
+            else if (w4[j]) {
+                put(w4[j] & 0xffu); put((w4[j] >> 8) & 0xffu);
+                put((w4[j] >> 16) & 0xffu); put(w4[j] >> 24);
+            }
+        }
+    }
+    if (blockIdx.x == 0)      // tail cells (fewer than one vector)
+        for (u64 i = lo + nvec * PER + threadIdx.x; i < hi; i += blockDim.x) put((u32)table[i]);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < KH_LHIST_BINS; i += blockDim.x) {
+        const u32 v = lh[i];
+        if (v) atomicAdd(&hist[i < hist_len ? i : hist_len - 1], (unsigned long long)v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -1399,4 +1456,26 @@ void kh_launch_unmix(int W, const void* in, void* out, u64 n, int k, hipStream_t
 void kh_launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n, 256)), dim3(256), 0, st, p, n, v);
+}
+
+void kh_launch_table_add(const void* keys, u64 n, int k, void* table, u32 cell_bytes, hipStream_t st) {
+    if (!n) return;
+    if (cell_bytes == 1)
+        hipLaunchKernelGGL((k_table_add<u8>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, st,
+                           reinterpret_cast<const KmerKey<1>*>(keys), n, k, reinterpret_cast<u8*>(table), 255u);
+    else
+        hipLaunchKernelGGL((k_table_add<u32>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, st,
+                           reinterpret_cast<const KmerKey<1>*>(keys), n, k, reinterpret_cast<u32*>(table),
+                           0xFFFFFFFFu);
+}
+void kh_launch_table_hist(const void* table, u32 cell_bytes, u64 lo, u64 hi, u32 cs,
+                          unsigned long long* hist, u32 hist_len, hipStream_t st) {
+    if (hi <= lo) return;
+    const u64 nvec = (hi - lo) / (16 / cell_bytes);
+    if (cell_bytes == 1)
+        hipLaunchKernelGGL((k_table_hist<u8>), dim3(grid_for(nvec, 256 * 4, 4096)), dim3(256), 0, st,
+                           reinterpret_cast<const u8*>(table), lo, hi, cs, hist, hist_len);
+    else
+        hipLaunchKernelGGL((k_table_hist<u32>), dim3(grid_for(nvec, 256 * 4, 4096)), dim3(256), 0, st,
+                           reinterpret_cast<const u32*>(table), lo, hi, cs, hist, hist_len);
 }

@@ -74,6 +74,16 @@ class EngineOps:
     def union_hist(self, sets, cs, hist_len):
         return self.eng.union_sum(sets, cs, hist_len=hist_len)
 
+    # -- direct-addressed occurrence table (k <= 16)
+    def table_add(self, s, table_t):
+        self.eng.table_add_set(s, table_t.data_ptr(), table_t.element_size())
+
+    def table_hist(self, table_t, lo, hi, cs, hist_len):
+        return self.eng.table_histogram(table_t.data_ptr(), table_t.element_size(), lo, hi, cs, hist_len)
+
+    def set_len(self, s):
+        return len(s)
+
 
 def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_len: int,
                               group=None) -> np.ndarray:
@@ -152,6 +162,63 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
     return ht.cpu().numpy().astype(np.uint64)
 
 
+TABLE_MAX_K = 16      # 4^16 one-byte cells = 4 GiB of the 288 GB
+
+
+def across_groups_table(ops, group_sets: Sequence, k: int, cs: int, hist_len: int, group=None) -> np.ndarray:
+    """Small-k form of the same histogram (BASELINE.json north_star "RCCL
+    all-reduce ... of the per-group unique-k-mer bitmaps"): every group set is a presence bitmap
+    over the 4^k canonical key values; the sum of the bitmaps, widened to one byte (four when
+    more than 255 groups exist), is accumulated locally in a direct-addressed table, all-reduced
+    (sum) across the ranks, and each rank histograms its 1/world of the cells; the small
+    histogram is all-reduced last.  Ring traffic is 2 * 4^k bytes per rank whatever the sets
+    hold, so this wins only while 4^k is small next to the keys the slot exchange would move:
+    `across_groups_auto` chooses."""
+    if k > TABLE_MAX_K:
+        raise ValueError(f"across_groups_table: k = {k} > {TABLE_MAX_K} has no direct-addressed table")
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = ops.device
+    cdev = getattr(ops, "comm_device", dev)
+    to_comm = getattr(ops, "to_comm", lambda t: t)
+    from_comm = getattr(ops, "from_comm", lambda t: t)
+    ng = torch.tensor([len(group_sets)], dtype=torch.int64, device=cdev)
+    dist.all_reduce(ng, op=dist.ReduceOp.SUM, group=group)
+    dtype = torch.uint8 if int(ng.item()) <= 255 else torch.int32
+    ncell = 4 ** k
+    table = torch.zeros(ncell, dtype=dtype, device=dev)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)           # the zero fill ran on torch's stream
+    for s in group_sets:
+        ops.table_add(s, table)
+    ops.flush()
+    tc = to_comm(table)
+    dist.all_reduce(tc, op=dist.ReduceOp.SUM, group=group)
+    table = from_comm(tc)
+    ops.before_wrap()
+    lo = (rank * ncell // world) // 16 * 16
+    hi = ncell if rank == world - 1 else ((rank + 1) * ncell // world) // 16 * 16
+    hist = np.asarray(ops.table_hist(table, lo, hi, cs, hist_len))
+    ht = torch.from_numpy(hist.astype(np.int64)).to(cdev)
+    dist.all_reduce(ht, op=dist.ReduceOp.SUM, group=group)
+    return ht.cpu().numpy().astype(np.uint64)
+
+
+def across_groups_auto(ops, group_sets: Sequence, k: int, cs: int, hist_len: int, group=None) -> np.ndarray:
+    """Table form when its ring traffic (2 * 4^k cells) is below what the slot exchange moves
+    (8 bytes per local key); the slot exchange otherwise.  The choice is made on the global
+    key count so that every rank takes the same branch."""
+    if k <= TABLE_MAX_K and hasattr(ops, "table_add"):
+        cdev = getattr(ops, "comm_device", ops.device)
+        nk = torch.tensor([sum(ops.set_len(s) for s in group_sets), len(group_sets)], dtype=torch.int64, device=cdev)
+        dist.all_reduce(nk, op=dist.ReduceOp.SUM, group=group)
+        world = dist.get_world_size(group)
+        cell = 1 if int(nk[1]) <= 255 else 4
+        if 2 * cell * 4 ** k < 8 * int(nk[0]) // world:
+            return across_groups_table(ops, group_sets, k, cs, hist_len, group)
+    return across_groups_distributed(ops, group_sets, k, cs, hist_len, group)
+
+
 def exp1_step(eng, seqs, group_of: Sequence[int], k: int, cs: int = 5000, hist_len: int = 5001,
               group=None):
     """One benchmark step on N GPUs: steps 1-6 locally, steps 7-8 through the exchange.
@@ -160,6 +227,6 @@ def exp1_step(eng, seqs, group_of: Sequence[int], k: int, cs: int = 5000, hist_l
     res = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len, want_sets=True, across=False)
     ops = EngineOps(eng, device, stage_on_host=dist.get_backend(group) == "gloo")
     gsets = [s.set_counts(1) for s in res["group_sets"]]
-    res["across_hist"] = across_groups_distributed(ops, gsets, k, cs, hist_len, group)
+    res["across_hist"] = across_groups_auto(ops, gsets, k, cs, hist_len, group)
     del res["group_sets"]
     return res

@@ -66,6 +66,9 @@ def load_library(path: Optional[str] = None):
         "kh_simple": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_uint32, C.POINTER(vp)]),
         "kh_histogram": (C.c_int, [vp, vp, u64p, C.c_uint32]),
         "kh_histogram_file": (C.c_int, [vp, vp, C.c_uint32, C.c_char_p]),
+        "kh_table_add_set": (C.c_int, [vp, vp, vp, C.c_uint32]),
+        "kh_table_histogram": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, u64p,
+                                         C.c_uint32]),
         "kh_dump_sorted": (C.c_int, [vp, vp, C.c_char_p]),
         "kh_set_free": (None, [vp]),
         "kh_set_info": (C.c_int, [vp, u64p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), u32p]),
@@ -100,7 +103,7 @@ ABI_SYMBOLS = [
     "kh_ctx_create", "kh_ctx_destroy", "kh_last_error", "kh_device_count", "kh_stats",
     "kh_profile_enable", "kh_stats_reset", "kh_sync", "kh_trim", "kh_build_batch", "kh_build_fasta",
     "kh_read_fasta", "kh_free_host", "kh_set_counts", "kh_union_sum", "kh_simple", "kh_histogram",
-    "kh_histogram_file", "kh_dump_sorted", "kh_set_free", "kh_set_info", "kh_set_counter_max",
+    "kh_histogram_file", "kh_table_add_set", "kh_table_histogram", "kh_dump_sorted", "kh_set_free", "kh_set_info", "kh_set_counter_max",
     "kh_set_download",
     "kh_set_upload", "kh_set_device_ptrs", "kh_set_from_device", "kh_set_export_device",
     "kh_set_export_range", "kh_set_wrap_device", "kh_set_partition_bounds",
@@ -366,6 +369,19 @@ class Engine:
         out = C.c_void_p()
         _check(self._lib.kh_set_wrap_device(self._ctx, k, n, keys_ptr, counts_ptr, uniform, C.byref(out)))
         return KmerSet(self, out.value)
+
+    # -- direct-addressed occurrence table (k <= 16)
+    def table_add_set(self, s: KmerSet, table_ptr: int, cell_bytes: int):
+        """table[v] += 1 (saturating) for every canonical k-mer v of `s`; `table_ptr` = device
+        memory of 4^k cells of `cell_bytes` (1 or 4).  Queued on the engine's stream."""
+        _check(self._lib.kh_table_add_set(self._ctx, s._h, table_ptr, cell_bytes))
+
+    def table_histogram(self, table_ptr: int, cell_bytes: int, lo: int, hi: int, cs: int,
+                        hist_len: int) -> np.ndarray:
+        hist = np.zeros(hist_len, dtype=np.uint64)
+        _check(self._lib.kh_table_histogram(self._ctx, table_ptr, cell_bytes, lo, hi, cs, _u64p(hist),
+                                            hist_len))
+        return hist
 
     def load(self, prefix: str) -> KmerSet:
         out = C.c_void_p()

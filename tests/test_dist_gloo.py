@@ -39,7 +39,8 @@ class OracleOps:
         return s[1] is not None
 
     def slot(self, keys, nparts):
-        top32 = keys >> np.uint64(2 * self.k - 32)
+        n = 2 * self.k
+        top32 = keys >> np.uint64(n - 32) if n >= 32 else keys << np.uint64(32 - n)
         return (top32 * np.uint64(nparts)) >> np.uint64(32)
 
     def partition_bounds(self, s, nparts):
@@ -72,18 +73,35 @@ class OracleOps:
         c = np.minimum(c, cs)
         return (u, c.astype(np.uint32)), np.bincount(np.minimum(c, hist_len - 1), minlength=hist_len).astype(np.uint64)
 
+    # direct-addressed occurrence table (small k)
+    def set_len(self, s):
+        return int(s[0].size)
 
-def group_db(species, n_genomes=2, length=4000):
+    def table_add(self, s, table_t):
+        from khoice_amd import engine as E
+        v = np.array([int(E.unmix_host(self.k, np.array([m], dtype=np.uint64))[0]) for m in s[0]], dtype=np.int64)
+        assert np.unique(v).size == v.size and (v < 4 ** self.k).all()
+        t = table_t.numpy()
+        t[v] += 1
+
+    def table_hist(self, table_t, lo, hi, cs, hist_len):
+        assert lo % 16 == 0
+        c = table_t.numpy()[lo:hi].astype(np.int64)
+        c = np.minimum(c[c > 0], min(cs, hist_len - 1))
+        return np.bincount(c, minlength=hist_len).astype(np.uint64)
+
+
+def group_db(species, n_genomes=2, length=4000, k=K):
     anc = synth.ancestor(species, length)
-    dbs = [O.set_counts(O.count_records([s.decode() for _, s in synth.genome_records(species, g, length, anc)], K), 1)
+    dbs = [O.set_counts(O.count_records([s.decode() for _, s in synth.genome_records(species, g, length, anc)], k), 1)
            for g in range(n_genomes)]
     return O.set_counts(O.union_sum(dbs, 5000), 1)
 
 
-def to_mixed(db):
+def to_mixed(db, k=K):
     from khoice_amd import engine as E
     keys = np.array(sorted(db), dtype=np.uint64)
-    mixed = np.array([int(E.mix_host(K, np.array([v], dtype=np.uint64))[0]) for v in keys], dtype=np.uint64)
+    mixed = np.array([int(E.mix_host(k, np.array([v], dtype=np.uint64))[0]) for v in keys], dtype=np.uint64)
     return np.sort(mixed), None
 
 
@@ -113,7 +131,7 @@ def test_across_groups_exchange_matches_single_process(layout, with_counts):
     procs = [ctx.Process(target=worker, args=(r, world, port, layout, with_counts, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=240) for _ in range(world)]
+    got = [q.get(timeout=90) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -122,3 +140,40 @@ def test_across_groups_exchange_matches_single_process(layout, with_counts):
     for _, h in got:
         assert h == want
     assert sum(want[2:]) > 0          # the shared block makes some k-mers multi-group
+
+
+def table_worker(rank, world, port, groups_per_rank, k, q):
+    from khoice_amd import dist as kdist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        ops = OracleOps(k, rank, world)
+        first = 1 + sum(groups_per_rank[:rank])
+        mine = [to_mixed(group_db(first + g, k=k), k) for g in range(groups_per_rank[rank])]
+        h_table = kdist.across_groups_table(ops, mine, k, 5000, 64)
+        h_slots = kdist.across_groups_distributed(ops, mine, k, 5000, 64)
+        h_auto = kdist.across_groups_auto(ops, mine, k, 5000, 64)
+        q.put((rank, h_table.tolist(), h_slots.tolist(), h_auto.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout,k", [([2, 2], 7), ([1, 0, 3], 9)])
+def test_small_k_table_all_reduce_matches_slot_exchange_and_oracle(layout, k):
+    """presence bitmaps summed by all-reduce == the slot exchange == the oracle."""
+    from khoice_amd import build as kbuild
+    kbuild.build_library()
+    world = len(layout)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=table_worker, args=(r, world, port, layout, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = O.histogram(O.union_sum([group_db(1 + g, k=k) for g in range(sum(layout))], 5000), 63)
+    for _, ht, hs, ha in got:
+        assert ht == want and hs == want and ha == want
+    assert sum(want[2:]) > 0

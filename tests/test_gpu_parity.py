@@ -321,8 +321,65 @@ def test_distributed_step_world1_matches_local(eng):
             assert (got["across_hist"] == want["across_hist"]).all()
             assert (got["within_hist"] == want["within_hist"]).all()
             assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+        # small k: the table form (all-reduce of summed presence bitmaps) and the automatic choice
+        ops = kdist.EngineOps(eng, torch.device("cuda", 0))
+        for k in (9, 13):
+            items = synth.species_set(3, 2, 60_000)
+            seqs = [t for _, _, t in items]
+            group_of = [s - 1 for s, _, _ in items]
+            want = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=5001, want_sets=True)
+            gsets = [g.set_counts(1) for g in want["group_sets"]]
+            assert (kdist.across_groups_table(ops, gsets, k, 5000, 5001) == want["across_hist"]).all()
+            assert (kdist.across_groups_distributed(ops, gsets, k, 5000, 5001) == want["across_hist"]).all()
+            assert (kdist.exp1_step(eng, seqs, group_of, k)["across_hist"] == want["across_hist"]).all()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,cell", [(5, 1), (11, 1), (11, 4), (15, 1), (16, 1)])
+def test_occurrence_table_matches_union_sum_and_oracle(eng, k, cell):
+    """kh_table_add_set / kh_table_histogram: cell v = number of sets holding
+    canonical k-mer v; histogram == the fused union-sum histogram == the oracle's."""
+    import torch
+    rng = random.Random(1000 + k)
+    base = random_dna(rng, 30_000)
+    texts = []
+    for g in range(4):
+        t = list(base)
+        for _ in range(300 * g):
+            t[rng.randrange(len(t))] = rng.choice("ACGT")
+        texts.append("".join(t) + "N" + random_dna(rng, 2_000 * g))
+    sets = [eng.build(t.encode(), k).set_counts(1) for t in texts]
+    table = torch.zeros(4 ** k, dtype=torch.uint8 if cell == 1 else torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    for s_ in sets:
+        eng.table_add_set(s_, table.data_ptr(), cell)
+    eng.sync()
+    dbs = [O.set_counts(O.count_records([t], k), 1) for t in texts]
+    udb = O.union_sum(dbs, 5000)
+    # the cells themselves
+    assert int(torch.count_nonzero(table)) == len(udb)
+    some = list(udb.items())[:2000]
+    idx = torch.tensor([key for key, _ in some], dtype=torch.int64, device="cuda:0")
+    assert table[idx].cpu().tolist() == [c for _, c in some]
+    _, hu = eng.union_sum(sets, 5000, hist_len=16)
+    want = np.array(O.histogram(udb, 15), dtype=np.uint64)
+    h = eng.table_histogram(table.data_ptr(), cell, 0, 4 ** k, 5000, 16)
+    assert (h == want).all() and int(h[0]) == 0
+    assert (h == hu).all()
+    # split ranges (what each rank histograms) add up; cs caps the counter like -cs does
+    if 4 ** k >= 64:
+        mid = (4 ** k // 3) // 16 * 16
+        h1 = eng.table_histogram(table.data_ptr(), cell, 0, mid, 5000, 16)
+        h2 = eng.table_histogram(table.data_ptr(), cell, mid, 4 ** k, 5000, 16)
+        assert (h1 + h2 == h).all()
+    hc = eng.table_histogram(table.data_ptr(), cell, 0, 4 ** k, 2, 16)
+    assert int(hc[1]) == int(h[1]) and int(hc[2]) == int(h[2:].sum()) and int(hc[3:].sum()) == 0
+    # a k above the table limit is refused, loudly
+    from khoice_amd.engine import KhoiceError
+    big = eng.build(texts[0].encode(), 21)
+    with pytest.raises(KhoiceError):
+        eng.table_add_set(big, table.data_ptr(), cell)
 
 
 def test_direct_and_staged_scatter_agree(eng, monkeypatch):
