@@ -122,6 +122,20 @@ int kh_histogram(kh_ctx *ctx, const kh_set *set, uint64_t *hist, uint32_t hist_l
 int kh_table_add_set(kh_ctx *ctx, const kh_set *set, void *d_table, uint32_t cell_bytes);
 int kh_table_histogram(kh_ctx *ctx, const void *d_table, uint32_t cell_bytes, uint64_t lo, uint64_t hi,
                        uint32_t cs, uint64_t *hist, uint32_t hist_len);
+/* ---------------------------------------------------------------- experiment type 4
+ * Replaces the text dumps + Python dict of src/merge_lists.py:14-33 (build_dictionary /
+ * update_dictionary; rules exp_type_4.smk:247-294): for every k-mer of `pivot` (with its count),
+ * which of `sets` hold it.  Outputs are HOST arrays in `dump -s` order (ascending canonical
+ * key): keys_out[n*W] (may be NULL), counts_out[n] (may be NULL), masks_out[n*nwords] with
+ * nwords = max(1, (nsets+63)/64), bit d%64 of word d/64 = "sets[d] holds the k-mer". */
+int kh_membership(kh_ctx *ctx, const kh_set *pivot, const kh_set *const *sets, int nsets,
+                  uint64_t *keys_out, uint32_t *counts_out, uint64_t *masks_out);
+/* One feature-level confusion-matrix row, summed in the reference's order and arithmetic
+ * (src/merge_lists.py:122-141): row[d] (d < nsets) = sum over pivot k-mers held by the sets M
+ * of 1/len(M)*count for d in M; *unique_pivot_count = sum of counts of k-mers no set holds. */
+int kh_confusion_row(kh_ctx *ctx, const kh_set *pivot, const kh_set *const *sets, int nsets,
+                     double *row, uint64_t *unique_pivot_count);
+
 /* text form consumed at exp_type_1.smk:210-212: lines "c<TAB>n", c = 1..cmax */
 int kh_histogram_file(kh_ctx *ctx, const kh_set *set, uint32_t cmax, const char *path);
 

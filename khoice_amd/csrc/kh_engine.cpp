@@ -786,6 +786,132 @@ extern "C" int kh_table_histogram(kh_ctx* c, const void* d_table, uint32_t cell_
     return KH_OK;
 }
 
+// ------------------------------------------------------------------- membership matrix
+// Experiment type 4 (src/merge_lists.py:14-33,101-141): which of `sets` hold each pivot k-mer.
+// Device: one search per (pivot key, set).  Host: the records are put in the order the
+// reference walks them — its dict is filled from the `dump -s` text, i.e. ascending canonical
+// key — because the floating-point row sums below depend on the order of the additions.
+namespace {
+struct KeyIdx { u64 key; u32 idx; };
+
+// ascending order of n canonical keys; W == 1: LSD radix over the 2k significant bits
+void canonical_order(int W, int k, const u64* keys, u64 n, std::vector<u32>& order) {
+    order.resize(n);
+    if (W == 2) {
+        for (u64 i = 0; i < n; ++i) order[i] = (u32)i;
+        std::sort(order.begin(), order.end(), [&](u32 a, u32 b) {
+            return keys[2 * (u64)a + 1] != keys[2 * (u64)b + 1] ? keys[2 * (u64)a + 1] < keys[2 * (u64)b + 1]
+                                                                : keys[2 * (u64)a] < keys[2 * (u64)b];
+        });
+        return;
+    }
+    std::vector<KeyIdx> a(n), b(n);
+    for (u64 i = 0; i < n; ++i) a[i] = KeyIdx{keys[i], (u32)i};
+    const int bits = 2 * k;
+    for (int sh = 0; sh < bits; sh += 11) {
+        size_t cnt[2049] = {0};
+        for (u64 i = 0; i < n; ++i) ++cnt[((a[i].key >> sh) & 2047) + 1];
+        for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
+        for (u64 i = 0; i < n; ++i) b[cnt[(a[i].key >> sh) & 2047]++] = a[i];
+        a.swap(b);
+    }
+    for (u64 i = 0; i < n; ++i) order[i] = a[i].idx;
+}
+
+struct Membership {
+    std::vector<u64> keys;     // canonical, as stored (mixed order)
+    std::vector<u32> counts;
+    std::vector<u64> masks;
+    std::vector<u32> order;    // ascending canonical key
+    u32 nwords = 0;
+};
+
+int membership_compute(kh_ctx* c, const kh_set* pivot, const kh_set* const* sets, int nsets, Membership& m) {
+    if (!c || !pivot || (nsets > 0 && !sets) || nsets < 0) return kh_fail(KH_E_ARG, "membership: bad argument");
+    if (pivot->n >> 32) return kh_fail(KH_E_ARG, "membership: pivot sets of 2^32 k-mers or more are not supported");
+    for (int i = 0; i < nsets; ++i) {
+        if (!sets[i]) return kh_fail(KH_E_ARG, "membership: NULL set");
+        if (sets[i]->k != pivot->k) return kh_fail(KH_E_KMISMATCH, "membership: k differs (%d vs %d)", sets[i]->k, pivot->k);
+    }
+    HIPCHK(hipSetDevice(c->dev));
+    const u64 n = pivot->n;
+    const int W = pivot->W;
+    m.nwords = (u32)std::max(1, (nsets + 63) / 64);
+    m.keys.assign(n * W, 0);
+    m.counts.assign(n, pivot->uniform);
+    m.masks.assign(n * m.nwords, 0);
+    if (!n) { m.order.clear(); return KH_OK; }
+    std::vector<KhSetView> v((size_t)std::max(nsets, 1));
+    for (int i = 0; i < nsets; ++i)
+        v[i] = KhSetView{sets[i]->n ? sets[i]->keys_ptr() : nullptr, nullptr, sets[i]->n, 1, 0};
+    Tmp d_view, d_masks, d_keys;
+    TMP_ALLOC(d_view, c, sizeof(KhSetView) * v.size());
+    TMP_ALLOC(d_masks, c, 8 * n * m.nwords);
+    TMP_ALLOC(d_keys, c, 8 * (u64)W * n);
+    HIPCHK(hipMemcpyAsync(d_view.b->p, v.data(), sizeof(KhSetView) * v.size(), hipMemcpyHostToDevice, c->st));
+    c->prof_begin(KC_SETOP);
+    kh_launch_membership(W, pivot->keys_ptr(), n, d_view.as<KhSetView>(), (u32)nsets, pivot->k, m.nwords,
+                         d_masks.as<u64>(), c->st);
+    c->prof_end();
+    kh_launch_unmix(W, pivot->keys_ptr(), d_keys.b->p, n, pivot->k, c->st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(m.masks.data(), d_masks.b->p, 8 * n * m.nwords, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(m.keys.data(), d_keys.b->p, 8 * (u64)W * n, hipMemcpyDeviceToHost, c->st));
+    if (pivot->cb)
+        HIPCHK(hipMemcpyAsync(m.counts.data(), pivot->counts_ptr(), 4 * n, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    canonical_order(W, pivot->k, m.keys.data(), n, m.order);
+    return KH_OK;
+}
+}  // namespace
+
+extern "C" int kh_membership(kh_ctx* c, const kh_set* pivot, const kh_set* const* sets, int nsets,
+                             uint64_t* keys_out, uint32_t* counts_out, uint64_t* masks_out) {
+    Membership m;
+    KHCHK(membership_compute(c, pivot, sets, nsets, m));
+    const int W = pivot->W;
+    for (u64 r = 0; r < pivot->n; ++r) {
+        const u64 i = m.order[r];
+        if (keys_out) for (int w = 0; w < W; ++w) keys_out[r * W + w] = m.keys[i * W + w];
+        if (counts_out) counts_out[r] = m.counts[i];
+        if (masks_out) for (u32 w = 0; w < m.nwords; ++w) masks_out[r * m.nwords + w] = m.masks[i * m.nwords + w];
+    }
+    return KH_OK;
+}
+
+// One row of the feature-level confusion matrix, exactly as src/merge_lists.py:122-141 adds it
+// up: k-mers in dump order; for a k-mer with count c held by the sets M (ascending index, the
+// order update_dictionary appends them, :26-33), row[m] += 1 / len(M) * c for m in M;
+// unique_pivot_count = sum of c over the k-mers no set holds (:122-126).
+extern "C" int kh_confusion_row(kh_ctx* c, const kh_set* pivot, const kh_set* const* sets, int nsets,
+                                double* row, uint64_t* unique_pivot_count) {
+#pragma clang fp contract(off)
+    if (!row || !unique_pivot_count) return kh_fail(KH_E_ARG, "kh_confusion_row: NULL output");
+    Membership m;
+    KHCHK(membership_compute(c, pivot, sets, nsets, m));
+    for (int d = 0; d < nsets; ++d) row[d] = 0.0;
+    u64 uniq = 0;
+    for (u64 r = 0; r < pivot->n; ++r) {
+        const u64 i = m.order[r];
+        int len = 0;
+        for (u32 w = 0; w < m.nwords; ++w) len += __builtin_popcountll(m.masks[i * m.nwords + w]);
+        if (!len) { uniq += m.counts[i]; continue; }
+        const double share = 1.0 / (double)len;              // Python: 1 / len(matches)
+        const double add = share * (double)m.counts[i];      //         ... * count
+        for (u32 w = 0; w < m.nwords; ++w) {
+            u64 bits = m.masks[i * m.nwords + w];
+            while (bits) {
+                const int d = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                volatile double sum = row[w * 64 + d] + add;
+                row[w * 64 + d] = sum;
+            }
+        }
+    }
+    *unique_pivot_count = uniq;
+    return KH_OK;
+}
+
 // ------------------------------------------------------------------------------ transfer
 extern "C" int kh_set_download(kh_ctx* c, const kh_set* s, uint64_t* keys, uint32_t* counts) {
     if (!c || !s) return kh_fail(KH_E_ARG, "kh_set_download: NULL argument");

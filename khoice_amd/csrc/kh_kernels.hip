@@ -1327,6 +1327,44 @@ __global__ __launch_bounds__(256) void k_table_hist(const C* __restrict__ table,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Membership matrix (experiment type 4, src/merge_lists.py:14-33): for every key of the pivot
+// set, bit d of its mask = "set d holds the key".  One thread per pivot key; every operand is
+// sorted by MIXED key and mixed keys are uniform, so the search starts from an interpolated
+// window of +-(4 sqrt(n) + 64) records and falls back to the whole set when the window misses.
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_membership(const KmerKey<W>* __restrict__ pivot, u64 n,
+                                                   const KhSetView* __restrict__ sets, u32 nsets, int k,
+                                                   u32 nwords, u64* __restrict__ masks) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const KmerKey<W> key = pivot[i];
+    const u64 top = (u64)kh_top32(key, k) << 32;
+    for (u32 w = 0; w < nwords; ++w) {
+        u64 m = 0;
+        const u32 dend = min(nsets, (w + 1) * 64);
+        for (u32 d = w * 64; d < dend; ++d) {
+            const KhSetView sv = sets[d];
+            if (!sv.n) continue;
+            const KmerKey<W>* __restrict__ keys = reinterpret_cast<const KmerKey<W>*>(sv.keys);
+            const u64 est = __umul64hi(top, sv.n);
+            const u64 rad = (u64)(4.0f * sqrtf((float)sv.n)) + 64;
+            u64 lo = est > rad ? est - rad : 0;
+            u64 hi = est + rad < sv.n ? est + rad : sv.n;
+            if (lo > 0 && !key_lt(keys[lo - 1], key)) lo = 0;        // answer lies left of the window
+            if (hi < sv.n && key_lt(keys[hi], key)) hi = sv.n;       // ... or right of it
+            while (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                if (key_lt(keys[mid], key)) lo = mid + 1; else hi = mid;
+            }
+            if (lo < sv.n && key_eq(keys[lo], key)) m |= 1ull << (d & 63);
+        }
+        masks[i * nwords + w] = m;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -1478,4 +1516,16 @@ void kh_launch_table_hist(const void* table, u32 cell_bytes, u64 lo, u64 hi, u32
     else
         hipLaunchKernelGGL((k_table_hist<u32>), dim3(grid_for(nvec, 256 * 4, 4096)), dim3(256), 0, st,
                            reinterpret_cast<const u32*>(table), lo, hi, cs, hist, hist_len);
+}
+
+void kh_launch_membership(int W, const void* pivot, u64 n, const KhSetView* sets, u32 nsets, int k,
+                          u32 nwords, u64* masks, hipStream_t st) {
+    if (!n) return;
+    const u32 grid = (u32)((n + 255) / 256);
+    if (W == 1)
+        hipLaunchKernelGGL((k_membership<1>), dim3(grid), dim3(256), 0, st,
+                           reinterpret_cast<const KmerKey<1>*>(pivot), n, sets, nsets, k, nwords, masks);
+    else
+        hipLaunchKernelGGL((k_membership<2>), dim3(grid), dim3(256), 0, st,
+                           reinterpret_cast<const KmerKey<2>*>(pivot), n, sets, nsets, k, nwords, masks);
 }

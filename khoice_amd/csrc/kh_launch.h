@@ -55,6 +55,8 @@ void kh_launch_histogram(const u32* counts, u64 n, unsigned long long* hist, u32
                          hipStream_t st);
 void kh_launch_unmix(int W, const void* in, void* out, u64 n, int k, hipStream_t st);
 void kh_launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st);
+void kh_launch_membership(int W, const void* pivot, u64 n, const KhSetView* sets, u32 nsets, int k,
+                          u32 nwords, u64* masks, hipStream_t st);
 void kh_launch_table_add(const void* keys, u64 n, int k, void* table, u32 cell_bytes, hipStream_t st);
 void kh_launch_table_hist(const void* table, u32 cell_bytes, u64 lo, u64 hi, u32 cs,
                           unsigned long long* hist, u32 hist_len, hipStream_t st);

@@ -66,6 +66,8 @@ def load_library(path: Optional[str] = None):
         "kh_simple": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_uint32, C.POINTER(vp)]),
         "kh_histogram": (C.c_int, [vp, vp, u64p, C.c_uint32]),
         "kh_histogram_file": (C.c_int, [vp, vp, C.c_uint32, C.c_char_p]),
+        "kh_membership": (C.c_int, [vp, vp, C.POINTER(vp), C.c_int, vp, vp, vp]),
+        "kh_confusion_row": (C.c_int, [vp, vp, C.POINTER(vp), C.c_int, C.POINTER(C.c_double), u64p]),
         "kh_table_add_set": (C.c_int, [vp, vp, vp, C.c_uint32]),
         "kh_table_histogram": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, u64p,
                                          C.c_uint32]),
@@ -103,7 +105,8 @@ ABI_SYMBOLS = [
     "kh_ctx_create", "kh_ctx_destroy", "kh_last_error", "kh_device_count", "kh_stats",
     "kh_profile_enable", "kh_stats_reset", "kh_sync", "kh_trim", "kh_build_batch", "kh_build_fasta",
     "kh_read_fasta", "kh_free_host", "kh_set_counts", "kh_union_sum", "kh_simple", "kh_histogram",
-    "kh_histogram_file", "kh_table_add_set", "kh_table_histogram", "kh_dump_sorted", "kh_set_free", "kh_set_info", "kh_set_counter_max",
+    "kh_histogram_file", "kh_membership", "kh_confusion_row",
+    "kh_table_add_set", "kh_table_histogram", "kh_dump_sorted", "kh_set_free", "kh_set_info", "kh_set_counter_max",
     "kh_set_download",
     "kh_set_upload", "kh_set_device_ptrs", "kh_set_from_device", "kh_set_export_device",
     "kh_set_export_range", "kh_set_wrap_device", "kh_set_partition_bounds",
@@ -369,6 +372,29 @@ class Engine:
         out = C.c_void_p()
         _check(self._lib.kh_set_wrap_device(self._ctx, k, n, keys_ptr, counts_ptr, uniform, C.byref(out)))
         return KmerSet(self, out.value)
+
+    # -- experiment type 4: membership of pivot k-mers in group sets
+    def membership(self, pivot: KmerSet, sets: Sequence[KmerSet]):
+        """(keys[n, W] canonical ascending, counts[n], masks[n, nwords]) — src/merge_lists.py:14-33
+        without the text dumps: bit d of a mask = sets[d] holds the k-mer."""
+        n, w = len(pivot), words_per_key(pivot.k)
+        nw = max(1, (len(sets) + 63) // 64)
+        keys = np.zeros((n, w), dtype=np.uint64)
+        counts = np.zeros(n, dtype=np.uint32)
+        masks = np.zeros((n, nw), dtype=np.uint64)
+        arr = (C.c_void_p * max(1, len(sets)))(*[s._h for s in sets])
+        _check(self._lib.kh_membership(self._ctx, pivot._h, arr, len(sets), keys.ctypes.data,
+                                       counts.ctypes.data, masks.ctypes.data))
+        return keys, counts, masks
+
+    def confusion_row(self, pivot: KmerSet, sets: Sequence[KmerSet]):
+        """(row[len(sets)] float64, unique_pivot_count) as src/merge_lists.py:122-141 adds them up."""
+        row = np.zeros(max(1, len(sets)), dtype=np.float64)
+        uniq = C.c_uint64(0)
+        arr = (C.c_void_p * max(1, len(sets)))(*[s._h for s in sets])
+        _check(self._lib.kh_confusion_row(self._ctx, pivot._h, arr, len(sets),
+                                          row.ctypes.data_as(C.POINTER(C.c_double)), C.byref(uniq)))
+        return row[:len(sets)], int(uniq.value)
 
     # -- direct-addressed occurrence table (k <= 16)
     def table_add_set(self, s: KmerSet, table_ptr: int, cell_bytes: int):

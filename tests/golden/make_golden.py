@@ -12,6 +12,9 @@ Sources executed:
   * workflow/rules/exp_type_1.smk:268-297  body of rule across_group_union_analysis
   * workflow/rules/exp_type_2.smk:171-216  summarize_histogram_type2
   * src/merge_lists.py                     get_canonical_kmer, process_read_into_kmers
+  * src/merge_lists.py main()              feature-level confusion matrix + accuracy values
+                                           (merge_lists.json; its text-dump inputs are written
+                                           by OUR oracle, the three output files by the reference)
 """
 import importlib.util
 import json
@@ -205,6 +208,62 @@ def gen_complex_ops():
     return {"k_values": k_values, "num_datasets": num_datasets, "listing": listing, "files": files}
 
 
+def _mutate(rng, seq, rate):
+    t = list(seq)
+    for i in range(len(t)):
+        if rng.random() < rate:
+            t[i] = rng.choice("ACGT")
+    return "".join(t)
+
+
+def gen_merge_lists(ml, rng):
+    """Run the reference's merge_lists.main (feature level) on exp_type_4-shaped text dumps."""
+    import argparse
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import kmer_oracle as O
+    cases = []
+    for num_datasets, k, length in [(2, 5, 500), (3, 11, 700), (4, 21, 800), (3, 33, 700), (5, 7, 400)]:
+        shared = "".join(rng.choice("ACGT") for _ in range(length // 3))
+        pivots, rests = [], []
+        for d in range(num_datasets):
+            anc = shared + "".join(rng.choice("ACGT") for _ in range(length - len(shared)))
+            rests.append([_mutate(rng, anc, 0.03) + "N" + _mutate(rng, anc[:60], 0.0) for _ in range(2)])
+            pivots.append(_mutate(rng, anc, 0.05))
+        pivot_dbs = [O.count_records([p], k) for p in pivots]                     # kmc -ci1 (counts kept)
+        unions = [O.set_counts(O.union_sum([O.set_counts(O.count_records([g], k), 1) for g in gs], 5000), 1)
+                  for gs in rests]                                                # exp_type_4.smk:160-214
+        with tempfile.TemporaryDirectory() as tmp:
+            os.makedirs(f"{tmp}/out/confusion_matrix")
+            os.makedirs(f"{tmp}/out/values")
+            pivot_paths, inter_paths, pivot_txt, inter_txt = [], [], [], []
+            for p in range(num_datasets):
+                path = f"{tmp}/pivot_{p + 1}.txt"
+                txt = O.dump_sorted_text(pivot_dbs[p], k)
+                open(path, "w").write(txt)
+                pivot_paths.append(path)
+                pivot_txt.append(txt)
+                for d in range(num_datasets):                                      # exp_type_4.smk:216-230
+                    ipath = f"{tmp}/pivot_{p + 1}_intersect_dataset_{d + 1}.txt"
+                    itxt = O.dump_sorted_text(O.intersect(unions[d], pivot_dbs[p], "sum", 255), k)
+                    open(ipath, "w").write(itxt)
+                    inter_paths.append(ipath)
+                    inter_txt.append(itxt)
+            open(f"{tmp}/pivots.txt", "w").write("".join(x + "\n" for x in pivot_paths))
+            open(f"{tmp}/inters.txt", "w").write("".join(x + "\n" for x in inter_paths))
+            ns = argparse.Namespace(num_datasets=num_datasets, pivot_filelist=f"{tmp}/pivots.txt",
+                                    intersect_list=f"{tmp}/inters.txt", output_path=f"{tmp}/out/",
+                                    k=str(k), read_level=None)
+            ml.args = ns            # calculate_accuracy_values reads the module-level `args`
+            ml.main(ns)
+            outs = {name: open(f"{tmp}/out/{name}").read() for name in (
+                f"confusion_matrix/k_{k}_confusion_matrix.txt",
+                f"confusion_matrix/k_{k}_confusion_matrix_with_unidentified.txt",
+                f"values/k_{k}_accuracy_values.csv")}
+        cases.append({"k": k, "num_datasets": num_datasets, "pivots": pivots, "rest_of_set": rests,
+                      "pivot_dumps": pivot_txt, "intersection_dumps": inter_txt, "outputs": outs})
+    return {"cases": cases}
+
+
 def main():
     s1, s2, ml = load_reference()
     rng = random.Random(0x6B686F696365)
@@ -214,6 +273,7 @@ def main():
         "canonical_kmers.json": gen_canonical(ml, rng),
         "exp1_csv.json": gen_csv(s1, rng),
         "complex_ops.json": gen_complex_ops(),
+        "merge_lists.json": gen_merge_lists(ml, random.Random(0x6D65726765)),
     }
     for name, obj in out.items():
         with open(os.path.join(HERE, name), "w") as fh:
