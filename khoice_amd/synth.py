@@ -159,6 +159,21 @@ def write_dataset_tree(root: str, n_species: int, n_genomes: int, length: int) -
                 fh.write(fasta_bytes(genome_records(s, g, length, anc)))
 
 
+def write_type4_tree(root: str, n_species: int, n_genomes: int, length: int) -> None:
+    """input_type4/{rest_of_set/dataset_{s}/*.fna.gz, pivot/pivot_{s}.fna.gz} as exp_type_4.smk:31-51
+    stages them (out-pivot: the pivot genome is NOT among its dataset's rest-of-set genomes)."""
+    os.makedirs(os.path.join(root, "input_type4", "pivot"), exist_ok=True)
+    for s in range(1, n_species + 1):
+        d = os.path.join(root, "input_type4", "rest_of_set", f"dataset_{s}")
+        os.makedirs(d, exist_ok=True)
+        anc = ancestor(s, length)
+        for g in range(n_genomes + 1):
+            path = (os.path.join(root, "input_type4", "pivot", f"pivot_{s}.fna.gz") if g == n_genomes
+                    else os.path.join(d, f"sp{s}_g{g}.fna.gz"))
+            with gzip.open(path, "wb", compresslevel=1) as fh:
+                fh.write(fasta_bytes(genome_records(s, g, length, anc)))
+
+
 def species_set(n_species: int, n_genomes: int, length: int, first_species: int = 1):
     """[(species, genome, cleaned sequence text)] for the device-resident benchmarks."""
     out = []

@@ -259,3 +259,30 @@ def test_concurrent_processes_share_the_gpu(tmp_path):
         srv.wait(timeout=30)
     dbs = [O.set_counts(O.build(open(os.path.join(root, n + ".fa"), "rb").read(), 31), 1) for n in names]
     assert open(os.path.join(root, "h.txt")).read() == O.histogram_text(O.union_sum(dbs, 5000), 65535)
+
+
+def test_exp_type_4_rule_by_rule_and_batched_match_oracle(tmp_path):
+    """exp_type_4.smk through bin/kmc, bin/kmc_tools and the merge_lists drop-in, and the batched
+    runner (no dumps, no intersections): both equal the oracle's direct answer, byte for byte."""
+    from khoice_amd.workflow import exp_type_4 as W4
+    from tests.test_workflow_cpu import expected_type4_outputs
+    root = str(tmp_path / "rules")
+    os.makedirs(root)
+    synth.write_type4_tree(root, 3, 2, 30_000)
+    out = W4.run(root, [21], 3)
+    root2 = str(tmp_path / "batched")
+    os.makedirs(root2)
+    synth.write_type4_tree(root2, 3, 2, 30_000)
+    out2 = W4.run_batched(root2, [9, 21, 41], 3)
+    assert out2["processes"] == 0
+    for k in (9, 21, 41):
+        want = expected_type4_outputs(root2, k, 3)
+        for rel, text in want.items():
+            assert open(os.path.join(root2, "accuracies_type_4", rel)).read() == text, (k, rel)
+            if k == 21:
+                assert open(os.path.join(root, "accuracies_type_4", rel)).read() == text, rel
+    assert open(out["accuracy_values"]).read() == expected_type4_outputs(root, 21, 3)["values/k_21_accuracy_values.csv"]
+    # the union histograms of the batched runner equal the rule's
+    for num in (1, 2, 3):
+        rel = f"unions_type_4/rest_of_set/k_21/dataset_{num}/dataset_{num}.hist.txt"
+        assert open(os.path.join(root, rel)).read() == open(os.path.join(root2, rel)).read()

@@ -61,3 +61,43 @@ def test_failed_rule_raises_and_leaves_no_output(tmp_path):
     else:
         raise AssertionError("expected the build rule to fail")
     assert not os.path.exists(os.path.join(root, "step_1/k_21/dataset_1/sp1_g0.kmc_pre"))
+
+
+def expected_type4_outputs(root, k, n):
+    """accuracies_type_4 texts from the FASTA files by the oracle alone (no rule plumbing)."""
+    from khoice_amd import merge_lists as ML
+    from khoice_amd.workflow import exp_type_4 as W4
+    from oracle import merge_oracle as MO
+    unions, pivots = [], []
+    for num in range(1, n + 1):
+        sets = [O.set_counts(O.build(O.read_fasta_bytes(
+            os.path.join(root, f"input_type4/rest_of_set/dataset_{num}/{g}.fna.gz")), k), 1)
+            for g in W4.rest_of_set(root, num)]
+        unions.append(O.set_counts(O.union_sum(sets, 5000), 1))
+        pivots.append(O.build(O.read_fasta_bytes(os.path.join(root, f"input_type4/pivot/pivot_{num}.fna.gz")), k))
+    rows, uniques = zip(*[MO.confusion_row(p, unions) for p in pivots])
+    cm, cm_ucol = ML.assemble_matrices(rows, uniques, n)
+    return ML.format_outputs(cm, cm_ucol, n, str(k))
+
+
+def test_exp_type_4_dag_through_standins(tmp_path):
+    """exp_type_4.smk rule by rule (build, set, union, D x D intersect, dumps, merge_lists)
+    with oracle-backed stand-ins; the result equals the oracle's direct answer."""
+    from khoice_amd.workflow import exp_type_4 as W4
+    root = str(tmp_path)
+    synth.write_type4_tree(root, 3, 2, 3000)
+    out = W4.run(root, [9, 21], 3, bin_dir=FAKE, merge_cmd=os.path.join(FAKE, "merge_lists"))
+    per_k = 3 * (2 * 2 + 1 + 3) + 3 * (1 + 3 * 3) + 1
+    assert out["processes"] == 2 * per_k
+    cat = ""
+    for k in (21, 9):          # `cat values/*.csv`: k_21_... sorts before k_9_...
+        want = expected_type4_outputs(root, k, 3)
+        for rel, text in want.items():
+            assert open(os.path.join(root, "accuracies_type_4", rel)).read() == text, rel
+        cat += want[f"values/k_{k}_accuracy_values.csv"]
+    assert open(out["accuracy_values"]).read() == cat
+    # intermediates the rules delete are gone, the file lists name absolute dump paths
+    assert not os.path.exists(os.path.join(root, "step_1_type_4/rest_of_set/k_21/dataset_1/sp1_g0.kmc_pre"))
+    assert not os.path.exists(os.path.join(root, "text_dump_type_4/k_21/pivot/pivot_1.txt"))
+    first = open(os.path.join(root, "filelists_type_4/k_21/intersections_filelist.txt")).readline().strip()
+    assert first == os.path.abspath(root) + "/text_dump_type_4/k_21/intersection/pivot_1/pivot_1_intersect_dataset_1.txt"
