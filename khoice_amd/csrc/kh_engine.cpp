@@ -117,6 +117,32 @@ struct Tmp {
                                      (size_t)(bytes));                                    \
     } while (0)
 
+void* kh_ctx::pin_alloc(size_t bytes, size_t* got) {
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    auto it = pinned_free.lower_bound(bytes);
+    if (it != pinned_free.end() && it->first <= 4 * bytes) {
+        void* p = it->second;
+        *got = it->first;
+        pinned_free.erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    *got = bytes;
+    return p;
+}
+void kh_ctx::pin_release(void* p, size_t bytes) {
+    if (p) pinned_free.emplace(bytes, p);
+}
+
+// KHOICE_TRACE=1: host-side timeline of kh_exp1_run on stderr (diagnostics only)
+#include <chrono>
+static bool g_trace = getenv("KHOICE_TRACE") != nullptr;
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static double g_t_build_submitted = 0, g_t_build_synced = 0;
+
 // ------------------------------------------------------------------------------ profiling
 void kh_ctx::prof_begin(int cls) {
     if (!profile) return;
@@ -191,6 +217,7 @@ extern "C" void kh_ctx_destroy(kh_ctx* c) {
     (void)hipStreamSynchronize(c->st);
     c->prof_collect();
     for (auto e : c->free_events) (void)hipEventDestroy(e);
+    for (auto& kv : c->pinned_free) (void)hipHostFree(kv.second);
     c->pool.trim();
     (void)hipStreamDestroy(c->st);
     delete c;
@@ -447,11 +474,19 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
 #endif
 
     // ---- read back set boundaries
-    std::vector<u64> desc((size_t)nb_total + 8);
-    HIPCHK(hipMemcpyAsync(desc.data(), d_lb.b->p, 8 * (u64)nb_total + 64, hipMemcpyDeviceToHost, st));
-    u64 nvalid = 0;
+    if (g_trace) g_t_build_submitted = now_ms();
+    struct Pin {
+        kh_ctx* c; void* p = nullptr; size_t bytes = 0;
+        ~Pin() { if (p) c->pin_release(p, bytes); }
+    } pin{c};
+    pin.p = c->pin_alloc(8 * (size_t)nb_total + 64 + 8, &pin.bytes);
+    if (!pin.p) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
+    u64* desc = static_cast<u64*>(pin.p);
+    u64& nvalid = desc[(size_t)nb_total + 8];
+    HIPCHK(hipMemcpyAsync(desc, d_lb.b->p, 8 * (u64)nb_total + 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&nvalid, d_bstart.as<u64>() + nb_total, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (g_trace) g_t_build_synced = now_ms();
     const u32 err = reinterpret_cast<const u32*>(&desc[nb_total])[1];
     if (err & KH_ERR_SPIN_TIMEOUT) return kh_fail(KH_E_INTERNAL, "look-back spin timed out in bucket sort");
     if (err & KH_ERR_CAPACITY) { *capacity_hit = true; return KH_OK; }
@@ -560,11 +595,16 @@ struct SetopJob {
     u64 total = 0, target = 0;
     DevBuf *okeys = nullptr, *ocnt = nullptr, *d_views = nullptr, *d_bounds = nullptr, *d_lb = nullptr,
            *d_hist = nullptr;
-    u64 tail[2] = {0, 0};
-    std::vector<KhSetView> views;   // host copy: must outlive the asynchronous upload
+    // pinned staging: [tail: 2 x u64][hist: hist_len x u64][views]; lives until the job dies
+    void* pin = nullptr;
+    size_t pin_bytes = 0;
+    u64* tail = nullptr;
+    u64* pin_hist = nullptr;
+    KhSetView* views = nullptr;
     ~SetopJob() {
         buf_unref(okeys); buf_unref(ocnt); buf_unref(d_views); buf_unref(d_bounds); buf_unref(d_lb);
         buf_unref(d_hist);
+        if (pin && c) c->pin_release(pin, pin_bytes);
     }
 };
 #define JOB_ALLOC(field, bytes)                                                              \
@@ -583,8 +623,15 @@ static int setop_prepare(SetopJob& j) {
         if (s->k != j.k) return kh_fail(KH_E_KMISMATCH, "operands built with different k (%d vs %d)", j.k, s->k);
     j.pay = !(j.op == KH_OP_UNION && j.mode == KH_OC_SUM);
     j.total = 0;
-    std::vector<KhSetView>& views = j.views;
-    views.resize(nsets);
+    if (!j.pin) {
+        j.pin = c->pin_alloc(16 + 8 * (size_t)j.hist_len + sizeof(KhSetView) * nsets, &j.pin_bytes);
+        if (!j.pin) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
+        j.tail = static_cast<u64*>(j.pin);
+        j.pin_hist = j.tail + 2;
+        j.views = reinterpret_cast<KhSetView*>(j.pin_hist + j.hist_len);
+    }
+    j.tail[0] = j.tail[1] = 0;
+    KhSetView* views = j.views;
     for (int g = 0; g < nsets; ++g) {
         views[g].keys = j.in[g]->n ? j.in[g]->keys_ptr() : nullptr;
         views[g].counts = j.in[g]->counts_ptr();
@@ -606,7 +653,7 @@ static int setop_prepare(SetopJob& j) {
     JOB_ALLOC(okeys, 8 * (size_t)j.W * j.total);
     JOB_ALLOC(ocnt, 4 * j.total);
     JOB_ALLOC(d_views, sizeof(KhSetView) * nsets);
-    HIPCHK(hipMemcpyAsync(j.d_views->p, views.data(), sizeof(KhSetView) * nsets, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(j.d_views->p, views, sizeof(KhSetView) * nsets, hipMemcpyHostToDevice, c->st));
     return KH_OK;
 }
 
@@ -648,7 +695,7 @@ static int setop_launch(SetopJob& j) {
     kh_debug_set_stamps(nullptr);
 #endif
     HIPCHK(hipMemcpyAsync(j.tail, lb.desc + (j.nranges - 1), 16, hipMemcpyDeviceToHost, st));
-    if (j.hist) HIPCHK(hipMemcpyAsync(j.hist, j.d_hist->p, 8 * (size_t)j.hist_len, hipMemcpyDeviceToHost, st));
+    if (j.hist) HIPCHK(hipMemcpyAsync(j.pin_hist, j.d_hist->p, 8 * (size_t)j.hist_len, hipMemcpyDeviceToHost, st));
     return KH_OK;
 }
 
@@ -669,6 +716,7 @@ static int setop_finish(SetopJob& j, kh_set** out) {
             buf_ref(j.ocnt);
             *out = make_set(j.k, n, j.okeys, 0, j.ocnt, 0, 1, j.cs);
             c->stat.setop_out += n;
+            if (j.hist) memcpy(j.hist, j.pin_hist, 8 * (size_t)j.hist_len);
             return KH_OK;
         }
         c->stat.retries++;
@@ -1118,6 +1166,8 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
     std::vector<u64> group_bases(ngroups, 0);
     for (int i = 0; i < nseq; ++i) group_bases[group_of[i]] += lens[i];
     int r = KH_OK;
+    const double t_begin = g_trace ? now_ms() : 0;
+    double t_unions_submitted = 0, t_unions_synced = 0, t_groups_done = 0;
     for (int g0 = 0; g0 < ngroups;) {
         int g1 = g0;
         u64 acc = 0;
@@ -1155,7 +1205,9 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
             if (r == KH_OK) r = setop_launch(j);
             if (r != KH_OK) { cleanup(); return r; }
         }
+        if (g_trace) t_unions_submitted = now_ms();
         if (hipStreamSynchronize(c->st) != hipSuccess) { cleanup(); return kh_fail(KH_E_HIP, "stream sync failed"); }
+        if (g_trace) t_unions_synced = now_ms();
         for (int g = g0; g < g1; ++g) {
             if (jobs[g - g0].in.empty()) continue;
             r = setop_finish(jobs[g - g0], &unions[g]);
@@ -1171,10 +1223,17 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
     }
     // steps 7+8 (skipped when the caller wants neither output: the multi-GPU path does them
     // after exchanging the group sets, khoice_amd/dist.py)
+    if (g_trace) t_groups_done = now_ms();
     if (across_hist || across_set) {
         r = kh_union_sum(c, usets.data(), ngroups, cs, &across, across_hist, hist_len);
         if (r != KH_OK) { cleanup(); return r; }
     }
+    if (g_trace)
+        fprintf(stderr, "[khoice trace] build submit %.3f wait %.3f | unions submit %.3f wait %.3f finish %.3f | "
+                        "across %.3f | total %.3f ms\n",
+                g_t_build_submitted - t_begin, g_t_build_synced - g_t_build_submitted,
+                t_unions_submitted - g_t_build_synced, t_unions_synced - t_unions_submitted,
+                t_groups_done - t_unions_synced, now_ms() - t_groups_done, now_ms() - t_begin);
     if (group_sets)
         for (int g = 0; g < ngroups; ++g) { group_sets[g] = unions[g]; unions[g] = nullptr; }
     if (across_set) { *across_set = across; across = nullptr; }

@@ -51,6 +51,11 @@ struct kh_ctx {
     double cls_ms[KC_COUNT] = {0};
     u64 cls_n[KC_COUNT] = {0};
     DevBuf* buf_alloc(size_t bytes);
+    // pinned host staging (small read-backs and descriptor uploads must not be pageable:
+    // a pageable hipMemcpyAsync waits for the stream and would serialise queued operations)
+    std::multimap<size_t, void*> pinned_free;
+    void* pin_alloc(size_t bytes, size_t* got);
+    void pin_release(void* p, size_t bytes);
     void prof_begin(int cls);
     void prof_end();
     void prof_collect();

@@ -176,14 +176,16 @@ def run(work_root: str, k_values: Sequence, num_datasets: int, bin_dir: Optional
 
 
 def run_batched(work_root: str, k_values: Sequence, num_datasets: int, device: int = 0,
-                keep_databases: bool = True):
+                keep_databases: bool = True, timings: Optional[dict] = None):
     """Same outputs as run(), produced by ONE resident engine: no process launches, no HIP
     re-initialisation, one batched build per k.  Intermediate databases (step_1..step_7) are
     still written when keep_databases is set, so a later Snakemake run finds them."""
+    import time
     from .. import engine as E
     k_values = [str(k) for k in k_values]
     prepare(work_root, k_values, num_datasets)
     eng = E.Engine(device)
+    t_start = time.perf_counter()
     try:
         genomes = {num: genomes_of(work_root, num) for num in range(1, num_datasets + 1)}
         group_of, names = [], []
@@ -197,6 +199,7 @@ def run_batched(work_root: str, k_values: Sequence, num_datasets: int, device: i
         with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
             texts = list(pool.map(
                 lambda ng: eng.read_fasta(os.path.join(work_root, f"data/dataset_{ng[0]}/{ng[1]}.fna.gz")), names))
+        t_ingest = time.perf_counter()
         for k in k_values:
             ki = int(k)
             counted = eng.build_batch(texts, ki, ci=1, with_counts=True)
@@ -225,8 +228,12 @@ def run_batched(work_root: str, k_values: Sequence, num_datasets: int, device: i
             across.histogram_file(65535, os.path.join(work_root, f"step_8/k_{k}/all_datasets_k{k}_hist.txt"))
             if keep_databases:
                 across.save(os.path.join(work_root, f"step_7/k_{k}/all_datasets.transformed.combined.transformed.combined"))
+        t_device = time.perf_counter()
     finally:
         eng.close()
     out = _csv_stage(work_root, k_values, num_datasets)
     out["processes"] = 0
+    if timings is not None:
+        timings.update(ingest_s=t_ingest - t_start, device_and_files_s=t_device - t_ingest,
+                       csv_s=time.perf_counter() - t_device, bases=sum(len(t) for t in texts))
     return out
