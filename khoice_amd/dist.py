@@ -26,6 +26,30 @@ import torch
 import torch.distributed as dist
 
 
+class _Trace:
+    """KHOICE_TRACE=1: wall time between the phases of one exchange, on stderr (rank 0)."""
+
+    def __init__(self, name):
+        import os
+        self.on = bool(os.environ.get("KHOICE_TRACE")) and (not dist.is_initialized() or dist.get_rank() == 0)
+        self.name, self.marks = name, []
+        if self.on:
+            import time
+            self.clock = time.perf_counter
+            self.t = self.clock()
+
+    def __call__(self, label):
+        if self.on:
+            now = self.clock()
+            self.marks.append(f"{label} {1e3 * (now - self.t):.3f}")
+            self.t = now
+
+    def report(self):
+        if self.on:
+            import sys
+            print(f"[khoice trace] {self.name}: " + " | ".join(self.marks) + " ms", file=sys.stderr)
+
+
 class EngineOps:
     """Engine side of the exchange for real runs: sets live in HBM, the exchange buffers are
     torch tensors on the same device, received slices are wrapped without copying."""
@@ -62,6 +86,13 @@ class EngineOps:
     def export_range(self, s, lo, hi, keys_t, counts_t):
         s.export_range(lo, hi, keys_t.data_ptr(), counts_t.data_ptr() if counts_t is not None else None)
 
+    def view_range(self, s, lo, hi):
+        """Zero-copy set over records [lo, hi) of `s` (the slice this rank keeps for itself)."""
+        keys_ptr, counts_ptr = s.device_ptrs()
+        w = self.words(s.k)
+        return self.eng.wrap_device(s.k, hi - lo, keys_ptr + lo * 8 * w,
+                                    counts_ptr + lo * 4 if counts_ptr else None, uniform=s.info()["uniform"])
+
     def flush(self):
         self.eng.sync()                       # export copies ran on the engine's stream
 
@@ -91,6 +122,7 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
     ALL ranks' groups (c saturating at cs).  Collective: every rank must call it."""
     world = dist.get_world_size(group)
     dev = ops.device
+    trace = _Trace("slots")
     cdev = getattr(ops, "comm_device", dev)          # where the collectives run
     to_comm = getattr(ops, "to_comm", lambda t: t)
     from_comm = getattr(ops, "from_comm", lambda t: t)
@@ -105,17 +137,24 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
     meta = torch.tensor([g_local, int(any(ops.has_counts(s) for s in group_sets))], dtype=torch.int64, device=cdev)
     metas = [torch.empty_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
+    trace("bounds+meta")
     g_all = [int(m[0]) for m in metas]
     with_counts = any(int(m[1]) for m in metas)
     g_max = max(max(g_all), 1)
-    # slice lengths, padded to g_max per destination
+    # slice lengths, padded to g_max per destination; the slice a rank owns itself never
+    # travels: it is used in place
+    rank = dist.get_rank(group)
+    keep_local = hasattr(ops, "view_range")
     send_len = np.zeros((world, g_max), dtype=np.int64)
     for g in range(g_local):
         send_len[:, g] = bounds[g][1:] - bounds[g][:-1]
+    if keep_local:
+        send_len[rank, :] = 0
     sl = torch.from_numpy(send_len.reshape(-1)).to(cdev)
     rl = torch.empty(world * g_max, dtype=torch.int64, device=cdev)
     dist.all_to_all_single(rl, sl, group=group)
     recv_len = rl.cpu().numpy().reshape(world, g_max)
+    trace("sizes")
     send_n = send_len.sum(axis=1)
     recv_n = recv_len.sum(axis=1)
     # pack: destination-major, group-minor
@@ -130,6 +169,7 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
                                  skeys[off * w:(off + n) * w], scnt[off:off + n] if with_counts else None)
             off += n
     ops.flush()
+    trace("pack")
     rkeys = torch.empty(int(recv_n.sum()) * w, dtype=torch.int64, device=cdev)
     dist.all_to_all_single(rkeys, to_comm(skeys), output_split_sizes=[int(n) * w for n in recv_n],
                            input_split_sizes=[int(n) * w for n in send_n], group=group)
@@ -141,8 +181,14 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
                                input_split_sizes=[int(n) for n in send_n], group=group)
         rcnt = from_comm(rcnt)
     ops.before_wrap()
+    trace("all_to_all")
     # every received slice is sorted, distinct and inside this rank's slot: union them in one pass
     slices = []
+    if keep_local:
+        for g in range(g_local):
+            lo, hi = int(bounds[g][rank]), int(bounds[g][rank + 1])
+            if hi > lo:
+                slices.append(ops.view_range(group_sets[g], lo, hi))
     off = 0
     for i in range(world):
         for g in range(g_max):
@@ -157,9 +203,13 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
     else:
         hist = np.zeros(hist_len, dtype=np.uint64)
     del slices
+    trace("union")
     ht = torch.from_numpy(hist.astype(np.int64)).to(cdev)
     dist.all_reduce(ht, op=dist.ReduceOp.SUM, group=group)
-    return ht.cpu().numpy().astype(np.uint64)
+    out = ht.cpu().numpy().astype(np.uint64)
+    trace("all_reduce")
+    trace.report()
+    return out
 
 
 TABLE_MAX_K = 16      # 4^16 one-byte cells = 4 GiB of the 288 GB

@@ -52,6 +52,10 @@ class OracleOps:
             c = s[1][lo:hi] if s[1] is not None else np.ones(hi - lo, dtype=np.uint32)
             counts_t.copy_(torch.from_numpy(c.view(np.int32).copy()))
 
+    def view_range(self, s, lo, hi):
+        assert (self.slot(s[0][lo:hi], self.world) == self.rank).all()
+        return s[0][lo:hi], (s[1][lo:hi] if s[1] is not None else None)
+
     def flush(self):
         pass
 
@@ -91,6 +95,9 @@ class OracleOps:
         return np.bincount(c, minlength=hist_len).astype(np.uint64)
 
 
+CopyAllOps = type("CopyAllOps", (OracleOps,), {"view_range": property()})   # hasattr() -> False
+
+
 def group_db(species, n_genomes=2, length=4000, k=K):
     anc = synth.ancestor(species, length)
     dbs = [O.set_counts(O.count_records([s.decode() for _, s in synth.genome_records(species, g, length, anc)], k), 1)
@@ -109,7 +116,7 @@ def worker(rank, world, port, groups_per_rank, with_counts, q):
     from khoice_amd import dist as kdist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        ops = OracleOps(K, rank, world)
+        ops = (CopyAllOps if with_counts else OracleOps)(K, rank, world)
         first = 1 + sum(groups_per_rank[:rank])
         mine = [to_mixed(group_db(first + g)) for g in range(groups_per_rank[rank])]
         if with_counts and mine:      # make one rank's sets carry counters: they must travel
