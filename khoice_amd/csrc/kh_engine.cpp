@@ -1138,6 +1138,57 @@ extern "C" int kh_sets_partition_bounds(kh_ctx* c, const kh_set* const* sets, in
 }
 
 // ------------------------------------------------------------------------------ fused exp 1
+// A group whose genomes do not fit the wave budget together ("HBM spill"):
+// its genomes are built in sub-waves, each summed into a running union that carries counters
+// (no saturation until the end), so the memory in flight is one sub-wave + the union.  The
+// final pass applies `cs` and takes the histogram.  Same result as the one-wave path.
+static int group_union_incremental(kh_ctx* c, const std::vector<int>& members, const uint8_t* const* seqs,
+                                   const uint64_t* lens, int on_device, int k, u32 cs, u64 budget,
+                                   uint64_t* hist, u32 hist_len, uint64_t* distinct_per_seq,
+                                   kh_set** out_union) {
+    kh_set* running = nullptr;
+    std::vector<kh_set*> wsets;
+    auto cleanup = [&]() {
+        for (auto* s : wsets) kh_set_free(s);
+        wsets.clear();
+        kh_set_free(running);
+        running = nullptr;
+    };
+    size_t i0 = 0;
+    while (i0 < members.size()) {
+        size_t i1 = i0;
+        u64 acc = 0;
+        while (i1 < members.size() && (i1 == i0 || acc + lens[members[i1]] <= budget) &&
+               i1 - i0 < (size_t)KH_MAX_INPUT_SETS - 1)
+            acc += lens[members[i1++]];
+        std::vector<const uint8_t*> wseqs(i1 - i0);
+        std::vector<uint64_t> wlens(i1 - i0);
+        wsets.assign(i1 - i0, nullptr);
+        for (size_t j = i0; j < i1; ++j) { wseqs[j - i0] = seqs[members[j]]; wlens[j - i0] = lens[members[j]]; }
+        int r = kh_build_batch(c, (int)(i1 - i0), wseqs.data(), wlens.data(), on_device, k, 1, KH_NO_MAX,
+                               KH_KMC_DEFAULT_CS, 0, wsets.data());
+        if (r != KH_OK) { cleanup(); return r; }
+        std::vector<const kh_set*> in;
+        if (running) in.push_back(running);
+        for (size_t j = i0; j < i1; ++j) {
+            if (distinct_per_seq) distinct_per_seq[members[j]] = wsets[j - i0]->n;
+            in.push_back(wsets[j - i0]);
+        }
+        kh_set* next = nullptr;
+        r = run_setop(c, in, KH_OP_UNION, KH_OC_SUM, 0x7fffffffu, &next, nullptr, 0);
+        if (r != KH_OK) { cleanup(); return r; }
+        for (auto* s : wsets) kh_set_free(s);
+        wsets.clear();
+        kh_set_free(running);
+        running = next;
+        i0 = i1;
+    }
+    std::vector<const kh_set*> in{running};
+    int r = run_setop(c, in, KH_OP_UNION, KH_OC_SUM, cs, out_union, hist, hist_len);
+    cleanup();
+    return r;
+}
+
 extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
                            int on_device, const int* group_of, int ngroups, int k, uint32_t cs,
                            uint64_t* within_hist, uint64_t* across_hist, uint32_t hist_len,
@@ -1161,7 +1212,14 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
     // k-mers would not fit HBM together): per wave, steps 1+2 build every genome of the wave as
     // a plain set in ONE batched launch sequence, steps 3+4+6 enqueue the wave's group unions
     // back to back before the host waits once; the genome sets are released before the next wave.
-    u64 budget = 24ull << 30;   // bases per wave (each costs ~40 bytes of HBM while in flight)
+    // A base in flight costs ~8W bytes in the partition array + 8W (+4) in the output arrays +
+    // its share of the group union: budget = 1/64 (W=1) or 1/96 (W=2) of the free HBM, in bases.
+    u64 budget = 4ull << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            budget = std::max<u64>(1u << 20, (free_b + c->pool.cached_bytes) / (k <= 32 ? 64 : 96));
+    }
     if (const char* e = getenv("KHOICE_WAVE_BASES")) budget = std::max<u64>(1, strtoull(e, nullptr, 10));
     std::vector<u64> group_bases(ngroups, 0);
     for (int i = 0; i < nseq; ++i) group_bases[group_of[i]] += lens[i];
@@ -1169,9 +1227,21 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
     const double t_begin = g_trace ? now_ms() : 0;
     double t_unions_submitted = 0, t_unions_synced = 0, t_groups_done = 0;
     for (int g0 = 0; g0 < ngroups;) {
+        if (group_bases[g0] > budget) {             // one group larger than a wave: sub-waves of genomes
+            std::vector<int> members;
+            for (int i = 0; i < nseq; ++i)
+                if (group_of[i] == g0) members.push_back(i);
+            r = group_union_incremental(c, members, seqs, lens, on_device, k, cs, budget,
+                                        within_hist ? within_hist + (size_t)g0 * hist_len : nullptr, hist_len,
+                                        distinct_per_seq, &unions[g0]);
+            if (r == KH_OK) r = kh_set_counts(c, unions[g0], 1, &usets[g0]);
+            if (r != KH_OK) { cleanup(); return r; }
+            ++g0;
+            continue;
+        }
         int g1 = g0;
         u64 acc = 0;
-        while (g1 < ngroups && (g1 == g0 || acc + group_bases[g1] <= budget)) acc += group_bases[g1++];
+        while (g1 < ngroups && acc + group_bases[g1] <= budget) acc += group_bases[g1++];
         std::vector<int> idx;                       // sequences of groups [g0, g1)
         for (int i = 0; i < nseq; ++i)
             if (group_of[i] >= g0 && group_of[i] < g1) idx.push_back(i);

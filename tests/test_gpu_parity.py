@@ -396,18 +396,34 @@ def test_direct_and_staged_scatter_agree(eng, monkeypatch):
 
 
 def test_exp1_group_waves_equal_single_wave(eng, monkeypatch):
-    """kh_exp1_run processes groups in memory-bounded waves; any wave size gives the same result."""
+    """kh_exp1_run processes groups in memory-bounded waves, and a group larger than a wave in
+    sub-waves of genomes summed into a running union (the HBM-spill path): any budget gives the
+    same result."""
     from khoice_amd import synth
-    items = synth.species_set(4, 2, 40_000)
-    seqs = [t for _, _, t in items]
-    group_of = [s - 1 for s, _, _ in items]
-    want = eng.exp1_run(seqs, group_of, 31, cs=5000, hist_len=64)
-    for budget in ("1", "90000", "170000"):      # one group per wave, two per wave, ...
-        monkeypatch.setenv("KHOICE_WAVE_BASES", budget)
-        got = eng.exp1_run(seqs, group_of, 31, cs=5000, hist_len=64)
-        assert (got["within_hist"] == want["within_hist"]).all()
-        assert (got["across_hist"] == want["across_hist"]).all()
-        assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+    for k, n_genomes in ((31, 2), (41, 5)):
+        items = synth.species_set(4, n_genomes, 40_000)
+        seqs = [t for _, _, t in items]
+        group_of = [s - 1 for s, _, _ in items]
+        want = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64)
+        # 1: one genome per sub-wave; 90000: two genomes per sub-wave (5-genome groups) or one
+        # group per wave (2-genome groups); 170000: two groups per wave / sub-waves of four
+        for budget in ("1", "90000", "170000"):
+            monkeypatch.setenv("KHOICE_WAVE_BASES", budget)
+            got = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64, want_sets=True)
+            assert (got["within_hist"] == want["within_hist"]).all()
+            assert (got["across_hist"] == want["across_hist"]).all()
+            assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+            monkeypatch.delenv("KHOICE_WAVE_BASES")
+            ref = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64, want_sets=True)
+            for a, b in zip(got["group_sets"], ref["group_sets"]):
+                ka, ca = a.download()
+                kb, cb = b.download()
+                assert (ka == kb).all() and (ca == cb).all()
+    # saturation is applied once, at the end: 6 identical genomes, cs = 4
+    monkeypatch.setenv("KHOICE_WAVE_BASES", "1")
+    seqs = [items[0][2]] * 6
+    got = eng.exp1_run(seqs, [0] * 6, 31, cs=4, hist_len=16)
+    assert int(got["within_hist"][0][4]) == int(got["distinct_per_seq"][0]) and int(got["within_hist"][0].sum()) == int(got["distinct_per_seq"][0])
 
 
 def test_long_sequences_are_chunked(eng, monkeypatch):
