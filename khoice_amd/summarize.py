@@ -180,3 +180,43 @@ def across_groups_csv(hist_paths: Sequence[str], num_datasets: int) -> str:
     for r in rows:
         r.append(round(r[8] / peak, 4))
     return _rows_to_csv(ACROSS_HEADER, rows)
+
+
+# --------------------------------------------------------------------------- experiment type 2
+PIVOT_WITHIN_HEADER = ("group_num,k,percent_1_occ,percent_25_or_less,percent_25_to_75,percent_75_or_more,"
+                       "unique_stat,unique_stat_norm,delta_frac,delta_frac_norm\n")
+PIVOT_ACROSS_HEADER = ("group_num,k,percent_1_occ,percent_2_to_3,percent_4_to_8,percent_9_more,"
+                       "unique_stat,unique_stat_norm,delta_frac,delta_frac_norm\n")
+
+
+def _pivot_rows(hist_paths: Sequence[str], num_datasets: int, members_of, across: bool) -> List[list]:
+    """`hist_paths` alternate subtract / intersect histograms in the order of
+    exp_type_2.smk:153-169 (dataset-major, then k); the group number and k are parsed from the
+    path as the rules do (:408-409, :527-528); the last column divides by the group's maximum."""
+    rows: List[list] = []
+    for i in range(0, len(hist_paths), 2):
+        parts = hist_paths[i].split("/")
+        num = parts[2].split("_")[1]
+        k = parts[1].split("_")[1]
+        sub = read_histogram_file(hist_paths[i])
+        inter = read_histogram_file(hist_paths[i + 1])
+        rows.append([f"group_{num}", k] + summarize_histogram_type2(sub, inter, members_of(num), across, int(k)))
+    for g in range(1, num_datasets + 1):
+        label = f"group_{g}"
+        peak = max(r[8] for r in rows if r[0] == label)
+        for r in rows:
+            if r[0] == label:
+                r.append(round(r[8] / peak, 4))
+    return rows
+
+
+def pivot_within_groups_csv(hist_paths: Sequence[str], num_datasets: int,
+                            members_of: Callable[[str], int]) -> str:
+    """within_dataset_analysis_type_2/within_dataset_analysis.csv (exp_type_2.smk:404-438)."""
+    return _rows_to_csv(PIVOT_WITHIN_HEADER, _pivot_rows(hist_paths, num_datasets, members_of, False))
+
+
+def pivot_across_groups_csv(hist_paths: Sequence[str], num_datasets: int) -> str:
+    """across_dataset_analysis_type_2/across_dataset_analysis.csv (exp_type_2.smk:521-554):
+    the member count passed to the summariser is num_datasets (:536)."""
+    return _rows_to_csv(PIVOT_ACROSS_HEADER, _pivot_rows(hist_paths, num_datasets, lambda _n: num_datasets, True))

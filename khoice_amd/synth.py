@@ -174,6 +174,21 @@ def write_type4_tree(root: str, n_species: int, n_genomes: int, length: int) -> 
                 fh.write(fasta_bytes(genome_records(s, g, length, anc)))
 
 
+def write_type2_tree(root: str, n_species: int, n_genomes: int, length: int) -> None:
+    """input_type_2/{rest_of_set/dataset_{s}/*.fna.gz, pivot/dataset_{s}/pivot_{s}.fna.gz}
+    (exp_type_2.smk:31-48)."""
+    for s in range(1, n_species + 1):
+        d = os.path.join(root, "input_type_2", "rest_of_set", f"dataset_{s}")
+        pd = os.path.join(root, "input_type_2", "pivot", f"dataset_{s}")
+        os.makedirs(d, exist_ok=True)
+        os.makedirs(pd, exist_ok=True)
+        anc = ancestor(s, length)
+        for g in range(n_genomes + 1):
+            path = os.path.join(pd, f"pivot_{s}.fna.gz") if g == n_genomes else os.path.join(d, f"sp{s}_g{g}.fna.gz")
+            with gzip.open(path, "wb", compresslevel=1) as fh:
+                fh.write(fasta_bytes(genome_records(s, g, length, anc)))
+
+
 def species_set(n_species: int, n_genomes: int, length: int, first_species: int = 1):
     """[(species, genome, cleaned sequence text)] for the device-resident benchmarks."""
     out = []

@@ -11,6 +11,8 @@ Sources executed:
   * workflow/rules/exp_type_1.smk:199-231  body of rule within_group_union_analysis
   * workflow/rules/exp_type_1.smk:268-297  body of rule across_group_union_analysis
   * workflow/rules/exp_type_2.smk:171-216  summarize_histogram_type2
+  * workflow/rules/exp_type_2.smk:404-438  body of rule within_group_analysis_exp_type2
+  * workflow/rules/exp_type_2.smk:521-554  body of rule across_group_analysis_exp_type2
   * src/merge_lists.py                     get_canonical_kmer, process_read_into_kmers
   * src/merge_lists.py main()              feature-level confusion matrix + accuracy values
                                            (merge_lists.json; its text-dump inputs are written
@@ -178,6 +180,53 @@ def gen_csv(s1, rng):
             "within_csv": within_csv, "across_csv": across_csv}
 
 
+def gen_csv2(s2, rng):
+    """Run the bodies of exp_type_2's two analysis `run:` blocks on synthetic histogram files."""
+    k_values = ["9", "21", "31"]
+    num_datasets = 3
+    members = {1: 2, 2: 5, 3: 12}
+    smk = f"{REF}/workflow/rules/exp_type_2.smk"
+    within_body = _lines(smk, 404, 438)
+    across_body = _lines(smk, 521, 554)
+    files = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            inputs = {"within": [], "across": []}
+            for scope, top in (("within", "within_dataset_results_type_2"), ("across", "across_dataset_results_type_2")):
+                for num in range(1, num_datasets + 1):          # exp_type_2.smk:153-169 order
+                    for k in k_values:
+                        n_bins = members[num] if scope == "within" else num_datasets - 1
+                        total = rng.randrange(1000, 4_000_000)
+                        sub = [rng.randrange(0, total)] + [0] * 254
+                        inter = [0] * 255
+                        for c in range(1, n_bins + 1):          # -ocsum counters are 1 + occurrences
+                            inter[c] = rng.randrange(0, total // n_bins + 1)
+                        for op, h in (("subtract", sub), ("intersect", inter)):
+                            p = f"{top}/k_{k}/dataset_{num}/{op}/dataset_{num}_pivot_{op}_group.hist.txt"
+                            os.makedirs(os.path.dirname(p), exist_ok=True)
+                            text = "".join(f"{i + 1}\t{v}\n" for i, v in enumerate(h))
+                            open(p, "w").write(text)
+                            files[p] = [(i, v) for i, v in enumerate(h) if v]
+                            inputs[scope].append(p)
+            os.makedirs("within_dataset_analysis_type_2")
+            os.makedirs("across_dataset_analysis_type_2")
+            ns = {"summarize_histogram_type2": s2, "num_datasets": num_datasets,
+                  "get_num_of_dataset_members_exp2": lambda d: members[int(d)],
+                  "input": inputs["within"], "output": ["within_dataset_analysis_type_2/within_dataset_analysis.csv"]}
+            exec(within_body, ns)
+            ns.update(input=inputs["across"], output=["across_dataset_analysis_type_2/across_dataset_analysis.csv"])
+            exec(across_body, ns)
+            within_csv = open("within_dataset_analysis_type_2/within_dataset_analysis.csv").read()
+            across_csv = open("across_dataset_analysis_type_2/across_dataset_analysis.csv").read()
+        finally:
+            os.chdir(cwd)
+    return {"k_values": k_values, "num_datasets": num_datasets, "members": {str(a): b for a, b in members.items()},
+            "hist_len": 255, "hists": files, "within_inputs": inputs["within"], "across_inputs": inputs["across"],
+            "within_csv": within_csv, "across_csv": across_csv}
+
+
 def gen_complex_ops():
     """Run the parse-time section exp_type_1.smk:26-84 in a scratch WORK_ROOT."""
     body = _lines(f"{REF}/workflow/rules/exp_type_1.smk", 26, 84)
@@ -274,6 +323,7 @@ def main():
         "exp1_csv.json": gen_csv(s1, rng),
         "complex_ops.json": gen_complex_ops(),
         "merge_lists.json": gen_merge_lists(ml, random.Random(0x6D65726765)),
+        "exp2_csv.json": gen_csv2(s2, random.Random(0x74797065)),
     }
     for name, obj in out.items():
         with open(os.path.join(HERE, name), "w") as fh:

@@ -286,3 +286,27 @@ def test_exp_type_4_rule_by_rule_and_batched_match_oracle(tmp_path):
     for num in (1, 2, 3):
         rel = f"unions_type_4/rest_of_set/k_21/dataset_{num}/dataset_{num}.hist.txt"
         assert open(os.path.join(root, rel)).read() == open(os.path.join(root2, rel)).read()
+
+
+def test_exp_type_2_rule_by_rule_and_batched_match_oracle(tmp_path):
+    """exp_type_2.smk (intersect -ocsum / kmers_subtract call sites, :354-380, :470-496) through
+    bin/kmc + bin/kmc_tools and through the batched runner: histogram files and both CSVs equal
+    the oracle's direct answer."""
+    from khoice_amd.workflow import exp_type_2 as W2
+    from tests.test_workflow_cpu import expected_type2_outputs
+    root = str(tmp_path / "rules")
+    os.makedirs(root)
+    synth.write_type2_tree(root, 3, 2, 30_000)
+    out = W2.run(root, [21], 3)
+    files, within, across = expected_type2_outputs(root, [21], 3, str(tmp_path / "exp1"))
+    for rel, text in files.items():
+        assert open(os.path.join(root, rel)).read() == text, rel
+    assert out["within"] == within and out["across"] == across
+    root2 = str(tmp_path / "batched")
+    os.makedirs(root2)
+    synth.write_type2_tree(root2, 3, 2, 30_000)
+    out2 = W2.run_batched(root2, [9, 21, 41], 3)
+    files2, within2, across2 = expected_type2_outputs(root2, [9, 21, 41], 3, str(tmp_path / "exp2"))
+    for rel, text in files2.items():
+        assert open(os.path.join(root2, rel)).read() == text, rel
+    assert out2["within"] == within2 and out2["across"] == across2 and out2["processes"] == 0

@@ -66,3 +66,21 @@ def test_csv_bytes_match_reference(golden, tmp_path, monkeypatch):
     across = S.across_groups_csv(g["across_inputs"], g["num_datasets"])
     assert within == g["within_csv"]
     assert across == g["across_csv"]
+
+
+def test_type2_csv_writers_match_reference_rule_bodies(tmp_path, monkeypatch):
+    """exp_type_2.smk:404-438 and :521-554 run on the same histogram files (golden/exp2_csv.json)."""
+    import json
+    import os
+    from khoice_amd import summarize as S
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "exp2_csv.json")))
+    monkeypatch.chdir(tmp_path)
+    for rel, nz in g["hists"].items():
+        h = [0] * g["hist_len"]
+        for i, v in nz:
+            h[i] = v
+        os.makedirs(os.path.dirname(rel), exist_ok=True)
+        open(rel, "w").write("".join(f"{i + 1}\t{v}\n" for i, v in enumerate(h)))
+    members = {int(a): b for a, b in g["members"].items()}
+    assert S.pivot_within_groups_csv(g["within_inputs"], g["num_datasets"], lambda n: members[int(n)]) == g["within_csv"]
+    assert S.pivot_across_groups_csv(g["across_inputs"], g["num_datasets"]) == g["across_csv"]

@@ -101,3 +101,58 @@ def test_exp_type_4_dag_through_standins(tmp_path):
     assert not os.path.exists(os.path.join(root, "text_dump_type_4/k_21/pivot/pivot_1.txt"))
     first = open(os.path.join(root, "filelists_type_4/k_21/intersections_filelist.txt")).readline().strip()
     assert first == os.path.abspath(root) + "/text_dump_type_4/k_21/intersection/pivot_1/pivot_1_intersect_dataset_1.txt"
+
+
+def expected_type2_outputs(root, k_values, n, exp_dir):
+    """Histogram texts and the two CSVs of experiment type 2 from the FASTA files by the oracle
+    (sets as dicts) and the golden-pinned summariser; nothing from the rule plumbing."""
+    from khoice_amd import summarize as S
+    from khoice_amd.workflow import exp_type_2 as W2
+    files = {}
+    for k in k_values:
+        unions, pivots = [], []
+        for num in range(1, n + 1):
+            sets = [O.set_counts(O.build(O.read_fasta_bytes(
+                os.path.join(root, f"input_type_2/rest_of_set/dataset_{num}/{g}.fna.gz")), k), 1)
+                for g in W2.rest_of_set(root, num)]
+            unions.append(O.union_sum(sets, 5000))
+            pivots.append(O.set_counts(O.build(O.read_fasta_bytes(
+                os.path.join(root, f"input_type_2/pivot/dataset_{num}/pivot_{num}.fna.gz")), k), 1))
+        group_sets = [O.set_counts(u, 1) for u in unions]
+        for num in range(n):
+            across = O.union_sum([group_sets[i] for i in range(n) if i != num], 5000)
+            for scope, other in (("within", unions[num]), ("across", across)):
+                for op, db in (("intersect", O.intersect(pivots[num], other, "sum")),
+                               ("subtract", O.kmers_subtract(pivots[num], other))):
+                    rel = f"{scope}_dataset_results_type_2/k_{k}/dataset_{num + 1}/{op}/dataset_{num + 1}_pivot_{op}_group.hist.txt"
+                    files[rel] = O.histogram_text(db, 255)
+    for rel, text in files.items():
+        os.makedirs(os.path.dirname(os.path.join(exp_dir, rel)), exist_ok=True)
+        open(os.path.join(exp_dir, rel), "w").write(text)
+    ks = [str(k) for k in k_values]
+    cwd = os.getcwd()
+    os.chdir(exp_dir)
+    try:
+        within = S.pivot_within_groups_csv(W2._hist_paths("within", ks, n), n, lambda d: len(W2.rest_of_set(root, int(d))))
+        across = S.pivot_across_groups_csv(W2._hist_paths("across", ks, n), n)
+    finally:
+        os.chdir(cwd)
+    return files, within, across
+
+
+def test_exp_type_2_dag_through_standins(tmp_path):
+    """exp_type_2.smk rule by rule with oracle-backed stand-ins == the oracle's direct answer."""
+    from khoice_amd.workflow import exp_type_2 as W2
+    root = str(tmp_path / "work")
+    os.makedirs(root)
+    synth.write_type2_tree(root, 3, 2, 3000)
+    out = W2.run(root, [9, 21], 3, bin_dir=FAKE)
+    assert out["processes"] == 2 * (3 * (2 * 2 + 2 + 1 + 4 + 1) + 3 * (1 + 4))
+    files, within, across = expected_type2_outputs(root, [9, 21], 3, str(tmp_path / "expected"))
+    for rel, text in files.items():
+        assert open(os.path.join(root, rel)).read() == text, rel
+    assert out["within"] == within and out["across"] == across
+    assert open(os.path.join(root, "within_dataset_analysis_type_2/within_dataset_analysis.csv")).read() == within
+    assert open(os.path.join(root, "across_dataset_analysis_type_2/across_dataset_analysis.csv")).read() == across
+    ops = open(os.path.join(root, "complex_ops_type_2/across_groups/k_9/pivot_2/across_datasets_pivot_2.txt")).read()
+    assert "dataset_2.transformed" not in ops and "set2 = within_databases_type_2/rest_of_set/k_9/dataset_3/" in ops
