@@ -94,13 +94,23 @@ DevBuf* kh_ctx::buf_alloc(size_t bytes) {
     b->bytes = got;
     b->refs = 1;
     b->ctx = this;
+    live_bufs.fetch_add(1);
     return b;
 }
 void buf_ref(DevBuf* b) { if (b) b->refs.fetch_add(1); }
 void buf_unref(DevBuf* b) {
     if (!b) return;
     if (b->refs.fetch_sub(1) == 1) {
-        if (b->ctx) b->ctx->pool.release(b->p, b->bytes);   // borrowed buffers have no ctx
+        if (kh_ctx* c = b->ctx) {                           // borrowed buffers have no ctx
+            if (!c->closed) {
+                c->pool.release(b->p, b->bytes);
+                c->live_bufs.fetch_sub(1);
+            } else {                                        // set freed after kh_ctx_destroy
+                (void)hipSetDevice(c->dev);
+                (void)hipFree(b->p);
+                if (c->live_bufs.fetch_sub(1) == 1) delete c;
+            }
+        }
         delete b;
     }
 }
@@ -218,9 +228,12 @@ extern "C" void kh_ctx_destroy(kh_ctx* c) {
     c->prof_collect();
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     for (auto& kv : c->pinned_free) (void)hipHostFree(kv.second);
+    c->pinned_free.clear();
     c->pool.trim();
     (void)hipStreamDestroy(c->st);
-    delete c;
+    c->st = nullptr;
+    c->closed = true;
+    if (c->live_bufs.load() == 0) delete c;
 }
 extern "C" int kh_sync(kh_ctx* c) {
     if (!c) return kh_fail(KH_E_ARG, "ctx is NULL");

@@ -50,6 +50,10 @@ struct kh_ctx {
     std::vector<hipEvent_t> free_events;
     double cls_ms[KC_COUNT] = {0};
     u64 cls_n[KC_COUNT] = {0};
+    // Sets may outlive kh_ctx_destroy (a binding's garbage collector frees them late): the
+    // context object stays behind as a closed shell until its last buffer is released.
+    std::atomic<long> live_bufs{0};
+    bool closed = false;
     DevBuf* buf_alloc(size_t bytes);
     // pinned host staging (small read-backs and descriptor uploads must not be pageable:
     // a pageable hipMemcpyAsync waits for the stream and would serialise queued operations)

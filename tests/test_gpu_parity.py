@@ -445,3 +445,20 @@ def test_long_sequences_are_chunked(eng, monkeypatch):
         sat = eng.build((b"A" * 30_000), k)
         monkeypatch.delenv("KHOICE_MAX_SEG_POS")
         assert set_to_db(sat) == {0: 255}
+
+
+def test_sets_may_outlive_their_engine():
+    """A binding's garbage collector may free set handles after kh_ctx_destroy: the context
+    stays behind as a closed shell until its last buffer is gone."""
+    from khoice_amd import engine as E
+    e = E.Engine(0)
+    s = e.build(("ACGTTGCA" * 500).encode(), 5)
+    t = s.set_counts(1)
+    u = e.union_sum([t, t], 5000)
+    e.close()
+    s.free()
+    del t
+    u.free()
+    e2 = E.Engine(0)
+    assert len(e2.build(b"ACGTACGTTTGA", 3)) > 0
+    e2.close()
