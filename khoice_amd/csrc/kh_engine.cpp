@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -608,7 +609,7 @@ struct SetopJob {
     u64 total = 0, target = 0;
     DevBuf *okeys = nullptr, *ocnt = nullptr, *d_views = nullptr, *d_bounds = nullptr, *d_lb = nullptr,
            *d_hist = nullptr;
-    // pinned staging: [tail: 2 x u64][hist: hist_len x u64][views]; lives until the job dies
+    // pinned staging: [tail: 3 x u64 = last descriptor | ticket, err | fullest slot][hist][views]
     void* pin = nullptr;
     size_t pin_bytes = 0;
     u64* tail = nullptr;
@@ -637,13 +638,13 @@ static int setop_prepare(SetopJob& j) {
     j.pay = !(j.op == KH_OP_UNION && j.mode == KH_OC_SUM);
     j.total = 0;
     if (!j.pin) {
-        j.pin = c->pin_alloc(16 + 8 * (size_t)j.hist_len + sizeof(KhSetView) * nsets, &j.pin_bytes);
+        j.pin = c->pin_alloc(24 + 8 * (size_t)j.hist_len + sizeof(KhSetView) * nsets, &j.pin_bytes);
         if (!j.pin) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
         j.tail = static_cast<u64*>(j.pin);
-        j.pin_hist = j.tail + 2;
+        j.pin_hist = j.tail + 3;
         j.views = reinterpret_cast<KhSetView*>(j.pin_hist + j.hist_len);
     }
-    j.tail[0] = j.tail[1] = 0;
+    j.tail[0] = j.tail[1] = j.tail[2] = 0;
     KhSetView* views = j.views;
     for (int g = 0; g < nsets; ++g) {
         views[g].keys = j.in[g]->n ? j.in[g]->keys_ptr() : nullptr;
@@ -660,9 +661,14 @@ static int setop_prepare(SetopJob& j) {
     j.empty = j.total == 0;
     if (j.empty) return KH_OK;
     j.cap = j.W == 1 ? (j.pay ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_W1) : (j.pay ? KH_SORT_CAP_PAY_W2 : KH_SORT_CAP_W2);
-    // mean fill 83 % of LDS capacity: a union of G sets holds up to G copies of a key, which
-    // widens the slot-size spread to sqrt(G) Poisson sigmas (90 % was measured to re-plan)
-    j.target = (u64)j.cap * 83 / 100;
+    // Mean slot fill T: a slot holds a Poisson number of distinct keys, each up to G = nsets
+    // times, so its size has sigma <= sqrt(T * G); T is the largest fill with T + 5 sigma <= cap
+    // (G = 5: 84 % of cap, G = 10: 78 %, G = 128: 42 %; 90 % at G = 5 was measured to re-plan).
+    {
+        const double zg = 5.0 * std::sqrt((double)std::max(1, nsets));
+        const double x = 0.5 * (-zg + std::sqrt(zg * zg + 4.0 * (double)j.cap));
+        j.target = std::max<u64>(16, std::min<u64>((u64)j.cap * 92 / 100, (u64)(x * x)));
+    }
     JOB_ALLOC(okeys, 8 * (size_t)j.W * j.total);
     JOB_ALLOC(ocnt, 4 * j.total);
     JOB_ALLOC(d_views, sizeof(KhSetView) * nsets);
@@ -707,7 +713,7 @@ static int setop_launch(SetopJob& j) {
     report_stamps(c, "setop", d_stamps.b, j.nranges);
     kh_debug_set_stamps(nullptr);
 #endif
-    HIPCHK(hipMemcpyAsync(j.tail, lb.desc + (j.nranges - 1), 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(j.tail, lb.desc + (j.nranges - 1), 24, hipMemcpyDeviceToHost, st));
     if (j.hist) HIPCHK(hipMemcpyAsync(j.pin_hist, j.d_hist->p, 8 * (size_t)j.hist_len, hipMemcpyDeviceToHost, st));
     return KH_OK;
 }
@@ -733,7 +739,11 @@ static int setop_finish(SetopJob& j, kh_set** out) {
             return KH_OK;
         }
         c->stat.retries++;
-        j.target = std::max<u64>(16, j.target / 4);
+        // the kernel recorded its fullest slot: shrink the mean fill so that one fits with 10 %
+        // to spare (never by less than 1/8, by 4 when the record is missing)
+        const u64 fullest = (u32)j.tail[2];
+        u64 next = fullest > j.cap ? j.target * j.cap * 9 / (fullest * 10) : j.target / 4;
+        j.target = std::max<u64>(16, std::min<u64>(next, j.target * 7 / 8));
         KHCHK(setop_launch(j));
         HIPCHK(hipStreamSynchronize(c->st));
     }

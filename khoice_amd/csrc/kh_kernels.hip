@@ -1145,7 +1145,10 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
     const u64 n64 = bcast[1];
     u32 n = 0;
     if (n64 > (u64)CAPC || n64 > (u64)cap) {
-        if (tid == 0) atomicOr(lb.err, KH_ERR_CAPACITY);
+        if (tid == 0) {
+            atomicOr(lb.err, KH_ERR_CAPACITY);
+            atomicMax(lb.err + 1, n64 > 0xffffffffull ? 0xffffffffu : (u32)n64);   // fullest slot seen
+        }
     } else {
         n = (u32)n64;
     }

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Throughput of the single-GPU BASELINE.json configs next to bench.py's headline:
+
+  cfg2  5 species x 5 genomes x 5 Mbp, k = 31: K1 build per genome (one call each) and batched
+        (one call for all 25), K4 histogram, against the C restatement on the host cores
+  cfg3  10 species x 10 genomes x 5 Mbp, k in {15, 21, 27, 31, 41}: fused within-group occurrence
+        (steps 1-4 of exp_type_1.smk, `kh_exp1_run` without the across-group step)
+
+Inputs are resident in HBM; every figure is the median of `--reps` timed repetitions after one
+warm-up.  One JSON object on stdout (committed as profiles/rNN_configs.json).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def timed(fn, reps, sync):
+    fn()
+    sync()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        sync()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--length", type=int, default=5_000_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    import torch
+    from khoice_amd import engine as E
+    from khoice_amd import synth
+    torch.cuda.init()
+    eng = E.Engine(0)
+    out = {"genome_bp": a.length, "reps": a.reps}
+
+    def resident(items):
+        dev = [torch.from_numpy(np.frombuffer(t, dtype=np.uint8).copy()).cuda() for _, _, t in items]
+        return dev, [(d.data_ptr(), d.numel()) for d in dev]
+
+    # ---------------------------------------------------------------- cfg2
+    items = synth.species_set(5, 5, a.length)
+    dev, seqs = resident(items)
+    t_batch, sets = timed(lambda: eng.build_batch(seqs, 31, ci=1, with_counts=True), a.reps, eng.sync)
+    distinct = sum(len(s) for s in sets)
+    t_single, _ = timed(lambda: [eng.build_batch([s], 31, ci=1, with_counts=True) for s in seqs], a.reps, eng.sync)
+    u = eng.union_sum([s.set_counts(1) for s in sets[:5]], 5000)
+    t_hist, _ = timed(lambda: u.histogram(5001), a.reps, eng.sync)
+    cfg2 = {"workload": f"5 x 5 x {a.length} bp, k=31", "distinct_kmers": distinct,
+            "k1_batched_ms": round(1e3 * t_batch, 3), "k1_batched_distinct_per_s": round(distinct / t_batch, 1),
+            "k1_per_genome_ms_total": round(1e3 * t_single, 3),
+            "k1_per_genome_distinct_per_s": round(distinct / t_single, 1),
+            "k4_histogram_ms": round(1e3 * t_hist, 4), "k4_counters": len(u)}
+    if not a.no_cpu:
+        from oracle import c_oracle as CO
+        texts = [t for s, _, t in items if s == 1]
+        t0 = time.perf_counter()
+        dbs = [CO.count(t, 31) for t in texts]
+        dt = time.perf_counter() - t0
+        cfg2["cpu_port_k1"] = {"distinct_per_s": round(sum(len(d) for d in dbs) / dt, 1), "cores": 1,
+                               "sample": "species 1 (5 genomes), oracle/kh_oracle.c kho_count, one thread"}
+        ok = all((d.arrays()[0] == s.download_sorted()[0]).all() for d, s in zip(dbs, sets[:5]))
+        cfg2["cpu_port_k1"]["keys_equal_to_gpu"] = bool(ok)
+    out["cfg2"] = cfg2
+    del sets, u, dev
+    eng.trim()
+
+    # ---------------------------------------------------------------- cfg3
+    items = synth.species_set(10, 10, a.length)
+    dev, seqs = resident(items)
+    group_of = [s - 1 for s, _, _ in items]
+    rows = []
+    for k in (15, 21, 27, 31, 41):
+        r0 = eng.stats()["retries"]
+        t, res = timed(lambda: eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=5001, across=False), max(2, a.reps // 2), eng.sync)
+        d = int(res["distinct_per_seq"].sum())
+        rows.append({"k": k, "ms": round(1e3 * t, 3), "replans_per_run": (eng.stats()["retries"] - r0) / (1 + max(2, a.reps // 2)),
+                     "distinct_kmers": d, "distinct_per_s": round(d / t, 1),
+                     "bases_per_s": round(sum(n for _, n in seqs) / t, 1)})
+    out["cfg3"] = {"workload": f"10 x 10 x {a.length} bp, steps 1-4 (within-group occurrence)", "per_k": rows}
+    print(json.dumps(out))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
