@@ -607,9 +607,9 @@ struct SetopJob {
     uint64_t* hist = nullptr;
     bool pay = false, empty = false;
     u64 total = 0, target = 0;
-    DevBuf *okeys = nullptr, *ocnt = nullptr, *d_views = nullptr, *d_bounds = nullptr, *d_lb = nullptr,
-           *d_hist = nullptr;
-    // pinned staging: [tail: 3 x u64 = last descriptor | ticket, err | fullest slot][hist][views]
+    DevBuf *okeys = nullptr, *ocnt = nullptr, *d_views = nullptr, *d_bounds = nullptr, *d_lb = nullptr;
+    // pinned staging, mirroring the device workspace from its last descriptor on:
+    // [last descriptor: 1 x u64][control: 8 x u64 = ticket, err | fullest slot | ...][hist][views]
     void* pin = nullptr;
     size_t pin_bytes = 0;
     u64* tail = nullptr;
@@ -617,7 +617,6 @@ struct SetopJob {
     KhSetView* views = nullptr;
     ~SetopJob() {
         buf_unref(okeys); buf_unref(ocnt); buf_unref(d_views); buf_unref(d_bounds); buf_unref(d_lb);
-        buf_unref(d_hist);
         if (pin && c) c->pin_release(pin, pin_bytes);
     }
 };
@@ -638,10 +637,10 @@ static int setop_prepare(SetopJob& j) {
     j.pay = !(j.op == KH_OP_UNION && j.mode == KH_OC_SUM);
     j.total = 0;
     if (!j.pin) {
-        j.pin = c->pin_alloc(24 + 8 * (size_t)j.hist_len + sizeof(KhSetView) * nsets, &j.pin_bytes);
+        j.pin = c->pin_alloc(72 + 8 * (size_t)j.hist_len + sizeof(KhSetView) * nsets, &j.pin_bytes);
         if (!j.pin) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
         j.tail = static_cast<u64*>(j.pin);
-        j.pin_hist = j.tail + 3;
+        j.pin_hist = j.tail + 9;
         j.views = reinterpret_cast<KhSetView*>(j.pin_hist + j.hist_len);
     }
     j.tail[0] = j.tail[1] = j.tail[2] = 0;
@@ -657,7 +656,6 @@ static int setop_prepare(SetopJob& j) {
     }
     c->stat.setops++;
     c->stat.setop_in += j.total;
-    if (j.hist) JOB_ALLOC(d_hist, 8 * (u64)j.hist_len);
     j.empty = j.total == 0;
     if (j.empty) return KH_OK;
     j.cap = j.W == 1 ? (j.pay ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_W1) : (j.pay ? KH_SORT_CAP_PAY_W2 : KH_SORT_CAP_W2);
@@ -685,13 +683,16 @@ static int setop_launch(SetopJob& j) {
     if (nr64 > 0x7fffffffull) return kh_fail(KH_E_ARG, "set operation too large for one launch");
     j.nranges = (u32)nr64;
     JOB_ALLOC(d_bounds, 8 * ((u64)j.nranges + 1) * nsets);
-    JOB_ALLOC(d_lb, 8 * (u64)j.nranges + 64);
+    // one workspace: [descriptors: nranges][control: 64 B][histogram: hist_len], zeroed by the
+    // range-bounds kernel and read back (from the last descriptor on) with one copy
+    const u64 hist_words = j.hist ? j.hist_len : 0;
+    const u64 lb_words = (u64)j.nranges + 8 + hist_words;
+    JOB_ALLOC(d_lb, 8 * lb_words);
     KhLookback lb;
     lb.desc = reinterpret_cast<u64*>(j.d_lb->p);
     lb.ticket = reinterpret_cast<u32*>(lb.desc + j.nranges);
     lb.err = lb.ticket + 1;
-    HIPCHK(hipMemsetAsync(j.d_lb->p, 0, 8 * (u64)j.nranges + 64, st));
-    if (j.hist) HIPCHK(hipMemsetAsync(j.d_hist->p, 0, 8 * (u64)j.hist_len, st));
+    unsigned long long* d_hist = j.hist ? reinterpret_cast<unsigned long long*>(lb.desc + j.nranges + 8) : nullptr;
 #ifdef KH_STAMPS
     Tmp d_stamps;
     TMP_ALLOC(d_stamps, c, 128 * (u64)j.nranges);
@@ -700,21 +701,19 @@ static int setop_launch(SetopJob& j) {
 #endif
     c->prof_begin(KC_RANGE_BOUNDS);
     kh_launch_range_bounds(j.W, reinterpret_cast<KhSetView*>(j.d_views->p), nsets, j.nranges, j.k,
-                           reinterpret_cast<u64*>(j.d_bounds->p), st);
+                           reinterpret_cast<u64*>(j.d_bounds->p), lb.desc, lb_words, st);
     c->prof_end();
     c->prof_begin(KC_SETOP);
     kh_launch_setop(j.W, j.pay, j.cap, reinterpret_cast<KhSetView*>(j.d_views->p), nsets,
                     reinterpret_cast<u64*>(j.d_bounds->p), j.nranges, j.k, j.op, j.mode, j.cs, j.okeys->p,
-                    reinterpret_cast<u32*>(j.ocnt->p), lb,
-                    j.hist ? reinterpret_cast<unsigned long long*>(j.d_hist->p) : nullptr, j.hist_len, st);
+                    reinterpret_cast<u32*>(j.ocnt->p), lb, d_hist, j.hist_len, st);
     c->prof_end();
     HIPCHK(hipGetLastError());
 #ifdef KH_STAMPS
     report_stamps(c, "setop", d_stamps.b, j.nranges);
     kh_debug_set_stamps(nullptr);
 #endif
-    HIPCHK(hipMemcpyAsync(j.tail, lb.desc + (j.nranges - 1), 24, hipMemcpyDeviceToHost, st));
-    if (j.hist) HIPCHK(hipMemcpyAsync(j.pin_hist, j.d_hist->p, 8 * (size_t)j.hist_len, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(j.tail, lb.desc + (j.nranges - 1), 8 * (9 + hist_words), hipMemcpyDeviceToHost, st));
     return KH_OK;
 }
 
@@ -1133,7 +1132,7 @@ extern "C" int kh_set_partition_bounds(kh_ctx* c, const kh_set* s, uint32_t npar
     TMP_ALLOC(d_view, c, sizeof v);
     TMP_ALLOC(d_bounds, c, 8 * ((u64)nparts + 1));
     HIPCHK(hipMemcpyAsync(d_view.b->p, &v, sizeof v, hipMemcpyHostToDevice, c->st));
-    kh_launch_range_bounds(s->W, d_view.as<KhSetView>(), 1, nparts, s->k, d_bounds.as<u64>(), c->st);
+    kh_launch_range_bounds(s->W, d_view.as<KhSetView>(), 1, nparts, s->k, d_bounds.as<u64>(), nullptr, 0, c->st);
     HIPCHK(hipMemcpyAsync(bounds, d_bounds.b->p, 8 * ((u64)nparts + 1), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     return KH_OK;
@@ -1154,7 +1153,7 @@ extern "C" int kh_sets_partition_bounds(kh_ctx* c, const kh_set* const* sets, in
     TMP_ALLOC(d_view, c, sizeof(KhSetView) * nsets);
     TMP_ALLOC(d_bounds, c, 8 * nb);
     HIPCHK(hipMemcpyAsync(d_view.b->p, v.data(), sizeof(KhSetView) * nsets, hipMemcpyHostToDevice, c->st));
-    kh_launch_range_bounds(W, d_view.as<KhSetView>(), nsets, nparts, k, d_bounds.as<u64>(), c->st);
+    kh_launch_range_bounds(W, d_view.as<KhSetView>(), nsets, nparts, k, d_bounds.as<u64>(), nullptr, 0, c->st);
     HIPCHK(hipMemcpyAsync(bounds, d_bounds.b->p, 8 * nb, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     return KH_OK;

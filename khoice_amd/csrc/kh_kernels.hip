@@ -1042,8 +1042,11 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
 // bounds[g * (nranges + 1) + r] = first index of set g whose key falls in slot >= r
 template <int W>
 __global__ void k_range_bounds(const KhSetView* __restrict__ sets, u32 nsets, u32 nranges, int k,
-                               u64* __restrict__ bounds) {
+                               u64* __restrict__ bounds, u64* __restrict__ zero, u64 zero_words) {
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    // the set operation that follows needs its look-back descriptors, control words and
+    // histogram zeroed: done here instead of by separate fill launches
+    for (u64 i = idx; i < zero_words; i += (u64)gridDim.x * blockDim.x) zero[i] = 0;
     const u64 per = (u64)nranges + 1;
     if (idx >= per * nsets) return;
     const u32 g = (u32)(idx / per), r = (u32)(idx % per);
@@ -1448,15 +1451,15 @@ void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const KhS
 }
 
 void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges, int k,
-                            u64* bounds, hipStream_t st) {
+                            u64* bounds, u64* zero, u64 zero_words, hipStream_t st) {
     const u64 total = ((u64)nranges + 1) * nsets;
     const u32 grid = (u32)((total + 255) / 256);
     if (W == 1)
         hipLaunchKernelGGL((k_range_bounds<1>), dim3(grid), dim3(256), 0, st, sets, nsets, nranges,
-                           k, bounds);
+                           k, bounds, zero, zero_words);
     else
         hipLaunchKernelGGL((k_range_bounds<2>), dim3(grid), dim3(256), 0, st, sets, nsets, nranges,
-                           k, bounds);
+                           k, bounds, zero, zero_words);
 }
 
 void kh_launch_setop(int W, bool pay, u32 cap, const KhSetView* sets, u32 nsets, const u64* bounds,

@@ -47,7 +47,7 @@ void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const KhS
                            void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
                            hipStream_t st);
 void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges, int k,
-                            u64* bounds, hipStream_t st);
+                            u64* bounds, u64* zero, u64 zero_words, hipStream_t st);
 void kh_launch_setop(int W, bool pay, u32 cap, const KhSetView* sets, u32 nsets, const u64* bounds,
                      u32 nranges, int k, int op, int mode, u32 cs, void* out_keys, u32* out_counts,
                      KhLookback lb, unsigned long long* hist, u32 hist_len, hipStream_t st);
