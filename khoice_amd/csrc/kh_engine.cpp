@@ -421,6 +421,8 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     TMP_ALLOC(d_thist, c, 4 * std::max<u64>(1, thist_n));
     TMP_ALLOC(d_tot, c, 8 * (u64)nb_total);
     TMP_ALLOC(d_bstart, c, 8 * ((u64)nb_total + 1));
+    Tmp d_scan;
+    TMP_ALLOC(d_scan, c, 8 * kh_exscan_tmp_words(nb_total));
     TMP_ALLOC(d_part, c, kb * std::max<u64>(1, total_pos));
     TMP_ALLOC(d_lb, c, 8 * (u64)nb_total + 64);
     DevBuf* okeys = c->buf_alloc(kb * std::max<u64>(1, total_pos));
@@ -457,7 +459,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     c->prof_end();
     c->prof_begin(KC_BUCKET_PLAN);
     kh_launch_col_totals(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_tot.as<u64>(), st);
-    kh_launch_exscan(d_tot.as<u64>(), d_bstart.as<u64>(), nb_total, st);
+    kh_launch_exscan(d_tot.as<u64>(), d_bstart.as<u64>(), nb_total, d_scan.as<u64>(), st);
     kh_launch_col_offsets(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(), st);
     c->prof_end();
     c->prof_begin(KC_EXTRACT_SCATTER);

@@ -396,34 +396,59 @@ __global__ void k_col_offsets(const KhSeg* __restrict__ segs, u32* __restrict__ 
 
 // exclusive scan of n u64 values by one 1024-thread block; out[n] = total.  Tiles of 1024
 // consecutive elements (coalesced), wave shuffles inside a tile, a running carry across tiles.
+// Exclusive scan of n u64 in two launches of n/4096 workgroups (one workgroup walking the
+// whole array took 100 us for the 67 K buckets of the benchmark batch): PHASE 0 writes each
+// tile's sum, PHASE 1 adds up the sums of the tiles before its own (redundantly, from L2) and
+// scans its tile.  out[n] = grand total.
+constexpr u32 KH_SCAN_TILE = 4096;
+template <int PHASE>
 __global__ __launch_bounds__(1024) void k_exscan(const u64* __restrict__ in, u64* __restrict__ out,
-                                                 u64 n) {
+                                                 u64 n, u64* __restrict__ tile_sum) {
     __shared__ u64 wsum[16];
+    __shared__ u64 tile_base;
     const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    u64 carry = 0;
-    for (u64 base = 0; base < n; base += 1024) {
-        const u64 i = base + tid;
-        const u64 v = i < n ? in[i] : 0ull;
-        u64 incl = v;
+    const u64 i0 = (u64)blockIdx.x * KH_SCAN_TILE + 4ull * tid;
+    u64 v[4], sum = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const u64 u = __shfl_up(incl, off);
-            if (lane >= (u32)off) incl += u;
-        }
-        if (lane == 63) wsum[wid] = incl;
-        __syncthreads();
-        u64 before = 0, total = 0;
-#pragma unroll
-        for (u32 w = 0; w < 16; ++w) {
-            const u64 x = wsum[w];
-            before += w < wid ? x : 0ull;
-            total += x;
-        }
-        if (i < n) out[i] = carry + before + incl - v;
-        carry += total;
-        __syncthreads();
+    for (int j = 0; j < 4; ++j) {
+        v[j] = i0 + j < n ? in[i0 + j] : 0ull;
+        sum += v[j];
     }
-    if (tid == 0) out[n] = carry;
+    u64 incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 u = __shfl_up(incl, off);
+        if (lane >= (u32)off) incl += u;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    if (PHASE == 1) {
+        u64 part = 0;
+        for (u32 t = tid; t < blockIdx.x; t += 1024) part += tile_sum[t];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (tid == 0) tile_base = 0;
+        __syncthreads();
+        if (lane == 0 && part) atomicAdd(reinterpret_cast<unsigned long long*>(&tile_base), (unsigned long long)part);
+    }
+    __syncthreads();
+    u64 before = 0, total = 0;
+#pragma unroll
+    for (u32 w = 0; w < 16; ++w) {
+        const u64 x = wsum[w];
+        before += w < wid ? x : 0ull;
+        total += x;
+    }
+    if (PHASE == 0) {
+        if (tid == 0) tile_sum[blockIdx.x] = total;
+        return;
+    }
+    u64 run = tile_base + before + incl - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (i0 + j < n) out[i0 + j] = run;
+        run += v[j];
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 1023) out[n] = run;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1427,8 +1452,11 @@ void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, 
     hipLaunchKernelGGL(k_col_offsets, dim3((max_nb + 255) / 256, nseg), dim3(256), 0, st, segs,
                        thist, bstart);
 }
-void kh_launch_exscan(const u64* in, u64* out, u64 n, hipStream_t st) {
-    hipLaunchKernelGGL(k_exscan, dim3(1), dim3(1024), 0, st, in, out, n);
+size_t kh_exscan_tmp_words(u64 n) { return (size_t)((n + KH_SCAN_TILE - 1) / KH_SCAN_TILE) + 1; }
+void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st) {
+    const u32 grid = (u32)std::max<u64>(1, (n + KH_SCAN_TILE - 1) / KH_SCAN_TILE);
+    hipLaunchKernelGGL((k_exscan<0>), dim3(grid), dim3(1024), 0, st, in, out, n, tmp);
+    hipLaunchKernelGGL((k_exscan<1>), dim3(grid), dim3(1024), 0, st, in, out, n, tmp);
 }
 
 void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const KhSeg* segs, u32 nseg,
