@@ -1249,16 +1249,34 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
         if (c <= 0) return 0u;
         return c > (long long)cs ? cs : (u32)c;
     };
+    // Fused histogram: almost every counter of a union is tiny (1 for the across-group sum,
+    // 1..G within a group), so a plain LDS histogram would serialise a whole wave on one
+    // address.  Counters below 16 go to 64 lane-private copies (the sort's work-list region is
+    // free by now) that are folded into lhist afterwards.
+    u32* stripe = tab + 128 + KH_FINE_BINS / 32;            // [16][64]
+    static_assert(KH_WORKLIST >= 16 * 64, "lane-private histogram needs the work-list region");
+    if (hist) {
+        __syncthreads();                                    // the sort is done with its work list
+        for (u32 i = tid; i < 16 * 64; i += nt) stripe[i] = 0;
+    }
     auto sink = [&](u64 o, const KmerKey<W>& key, u32 c) {
         out_keys[o] = key;
         if (out_counts) out_counts[o] = c;
         if (hist) {
-            if (c < KH_LHIST_BINS) atomicAdd(&lhist[c], 1u);
+            if (c < 16u) atomicAdd(&stripe[c * 64 + lane], 1u);
+            else if (c < KH_LHIST_BINS) atomicAdd(&lhist[c], 1u);
             else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
         }
     };
     rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch, op == KH_OP_UNION && mode != KH_OC_DIFF);
     if (hist) {
+        __syncthreads();
+        for (u32 c = tid >> 6; c < 16; c += nt >> 6) {      // one wave folds two counters
+            u32 v = stripe[c * 64 + lane];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && v) atomicAdd(&lhist[c], v);
+        }
         __syncthreads();
         for (u32 i = tid; i < KH_LHIST_BINS; i += nt) {
             const u32 v = lhist[i];
