@@ -1288,23 +1288,46 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
 // ------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------
+// Block-private histogram whose low bins (where nearly all counters of a k-mer database fall)
+// are kept once per lane, so that a wave does not serialise on one LDS address.
+struct BlockHist {
+    u32* lh;       // [KH_LHIST_BINS]
+    u32* stripe;   // [16][64]
+    __device__ void clear() {
+        for (u32 i = threadIdx.x; i < KH_LHIST_BINS; i += blockDim.x) lh[i] = 0;
+        for (u32 i = threadIdx.x; i < 16 * 64; i += blockDim.x) stripe[i] = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void add(u32 c, unsigned long long* hist, u32 hist_len) {
+        if (c < 16u) atomicAdd(&stripe[c * 64 + (threadIdx.x & 63)], 1u);
+        else if (c < KH_LHIST_BINS) atomicAdd(&lh[c], 1u);
+        else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
+    }
+    __device__ void flush(unsigned long long* hist, u32 hist_len) {
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < 16; i += blockDim.x) {
+            u32 v = 0;
+            for (u32 l = 0; l < 64; ++l) v += stripe[i * 64 + ((l + i) & 63)];
+            lh[i] += v;
+        }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < KH_LHIST_BINS; i += blockDim.x) {
+            const u32 v = lh[i];
+            if (v) atomicAdd(&hist[i < hist_len ? i : hist_len - 1], (unsigned long long)v);
+        }
+    }
+};
+
 __global__ __launch_bounds__(256) void k_histogram(const u32* __restrict__ counts, u64 n,
                                                   unsigned long long* __restrict__ hist,
                                                   u32 hist_len) {
     __shared__ u32 lh[KH_LHIST_BINS];
-    for (u32 i = threadIdx.x; i < KH_LHIST_BINS; i += blockDim.x) lh[i] = 0;
-    __syncthreads();
+    __shared__ u32 stripe[16 * 64];
+    BlockHist bh{lh, stripe};
+    bh.clear();
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const u32 c = counts[i];
-        if (c < KH_LHIST_BINS) atomicAdd(&lh[c], 1u);
-        else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
-    }
-    __syncthreads();
-    for (u32 i = threadIdx.x; i < KH_LHIST_BINS; i += blockDim.x) {
-        const u32 v = lh[i];
-        if (v) atomicAdd(&hist[i < hist_len ? i : hist_len - 1], (unsigned long long)v);
-    }
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) bh.add(counts[i], hist, hist_len);
+    bh.flush(hist, hist_len);
 }
 
 template <int W, bool UNMIX>
@@ -1342,17 +1365,16 @@ template <class C>
 __global__ __launch_bounds__(256) void k_table_hist(const C* __restrict__ table, u64 lo, u64 hi, u32 cs,
                                                    unsigned long long* __restrict__ hist, u32 hist_len) {
     __shared__ u32 lh[KH_LHIST_BINS];
-    for (u32 i = threadIdx.x; i < KH_LHIST_BINS; i += blockDim.x) lh[i] = 0;
-    __syncthreads();
+    __shared__ u32 stripe[16 * 64];
+    BlockHist bh{lh, stripe};
+    bh.clear();
     constexpr u32 PER = 16 / sizeof(C);
     const u64 nvec = (hi - lo) / PER;
     const uint4* __restrict__ vp = reinterpret_cast<const uint4*>(table + lo);
     const u64 stride = (u64)gridDim.x * blockDim.x;
     auto put = [&](u32 c) {
         if (!c) return;
-        if (c > cs) c = cs;
-        if (c < KH_LHIST_BINS) atomicAdd(&lh[c], 1u);
-        else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
+        bh.add(c > cs ? cs : c, hist, hist_len);
     };
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
         const uint4 q = vp[i];
@@ -1369,13 +1391,8 @@ __global__ __launch_bounds__(256) void k_table_hist(const C* __restrict__ table,
     }
     if (blockIdx.x == 0)      // tail cells (fewer than one vector)
         for (u64 i = lo + nvec * PER + threadIdx.x; i < hi; i += blockDim.x) put((u32)table[i]);
-    __syncthreads();
-    for (u32 i = threadIdx.x; i < KH_LHIST_BINS; i += blockDim.x) {
-        const u32 v = lh[i];
-        if (v) atomicAdd(&hist[i < hist_len ? i : hist_len - 1], (unsigned long long)v);
-    }
+    bh.flush(hist, hist_len);
 }
-
 
 // ------------------------------------------------------------------------------------------
 // Membership matrix (experiment type 4, src/merge_lists.py:14-33): for every key of the pivot
