@@ -460,7 +460,8 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     c->prof_begin(KC_BUCKET_PLAN);
     kh_launch_col_totals(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_tot.as<u64>(), st);
     kh_launch_exscan(d_tot.as<u64>(), d_bstart.as<u64>(), nb_total, d_scan.as<u64>(), st);
-    kh_launch_col_offsets(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(), st);
+    kh_launch_col_offsets(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(),
+                          d_tot.as<u32>() /* free after the scan */, st);
     c->prof_end();
     c->prof_begin(KC_EXTRACT_SCATTER);
     kh_launch_extract(W, true, d_seq.as<u8>(), d_segs.as<KhSeg>(), d_tiles.as<KhTile>(), ntiles,
@@ -480,7 +481,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     kh_debug_set_stamps(d_stamps.as<u64>());
 #endif
     c->prof_begin(KC_BUCKET_SORT);
-    kh_launch_bucket_sort(W, d_part.b->p, d_bstart.as<u64>(), d_segs.as<KhSeg>(), (u32)nseq, nb_total, k, okeys->p,
+    kh_launch_bucket_sort(W, d_part.b->p, d_bstart.as<u64>(), d_tot.as<u32>(), nb_total, k, okeys->p,
                           ocnt ? reinterpret_cast<u32*>(ocnt->p) : nullptr, lb, ci, cx, cs, st);
     c->prof_end();
     HIPCHK(hipGetLastError());

@@ -381,10 +381,13 @@ __global__ void k_col_totals(const KhSeg* __restrict__ segs, const u32* __restri
 }
 // turn per-tile counts into per-tile write cursors, relative to the segment's first bucket
 __global__ void k_col_offsets(const KhSeg* __restrict__ segs, u32* __restrict__ thist,
-                              const u64* __restrict__ bstart) {
+                              const u64* __restrict__ bstart, u32* __restrict__ bucket_nb) {
     const KhSeg sg = segs[blockIdx.y];
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= sg.nbuckets) return;
+    // pass C needs, per bucket, the bucket count of its segment (the fine-bin scale): one
+    // broadcast load there instead of a search through the segment table
+    bucket_nb[sg.bucket_base + b] = sg.nbuckets;
     u64 running = bstart[sg.bucket_base + b] - bstart[sg.bucket_base];
     for (u32 t = 0; t < sg.ntiles; ++t) {
         const u64 at = sg.thist_base + (u64)t * sg.nbuckets + b;
@@ -394,8 +397,6 @@ __global__ void k_col_offsets(const KhSeg* __restrict__ segs, u32* __restrict__ 
     }
 }
 
-// exclusive scan of n u64 values by one 1024-thread block; out[n] = total.  Tiles of 1024
-// consecutive elements (coalesced), wave shuffles inside a tile, a running carry across tiles.
 // Exclusive scan of n u64 in two launches of n/4096 workgroups (one workgroup walking the
 // whole array took 100 us for the 67 K buckets of the benchmark batch): PHASE 0 writes each
 // tile's sum, PHASE 1 adds up the sums of the tiles before its own (redundantly, from L2) and
@@ -951,7 +952,7 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
 template <int W>
 __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_bucket_sort_rle(
     const KmerKey<W>* __restrict__ part, const u64* __restrict__ bstart,
-    const KhSeg* __restrict__ segs, u32 nseg, u32 cap, int k, KmerKey<W>* __restrict__ out_keys,
+    const u32* __restrict__ bucket_nb, u32 cap, int k, KmerKey<W>* __restrict__ out_keys,
     u32* __restrict__ out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     const SortLds L{lds_raw, cap, W, false};
@@ -966,20 +967,10 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
 
     const u32 tid = threadIdx.x, nt = blockDim.x;
     distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
-    if (tid == 0) {
-        const u32 t = atomicAdd(lb.ticket, 1u);
-        scratch[16] = t;
-        // owning segment of global bucket t: last segment with bucket_base <= t
-        u32 a = 0, b = nseg;
-        while (b - a > 1) {
-            const u32 m = (a + b) >> 1;
-            if (segs[m].bucket_base <= t) a = m; else b = m;
-        }
-        scratch[17] = segs[a].nbuckets;
-    }
+    if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
     __syncthreads();
     const u32 q = scratch[16];
-    const u32 seg_nb = scratch[17];
+    const u32 seg_nb = bucket_nb[q];
     const u64 lo = bstart[q], hi = bstart[q + 1];
     const u64 n64 = hi - lo;
     KH_STAMP(q, 0);
@@ -1482,10 +1473,10 @@ void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* th
                        thist, tot);
 }
 void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
-                           hipStream_t st) {
+                           u32* bucket_nb, hipStream_t st) {
     if (!nseg || !max_nb) return;
     hipLaunchKernelGGL(k_col_offsets, dim3((max_nb + 255) / 256, nseg), dim3(256), 0, st, segs,
-                       thist, bstart);
+                       thist, bstart, bucket_nb);
 }
 size_t kh_exscan_tmp_words(u64 n) { return (size_t)((n + KH_SCAN_TILE - 1) / KH_SCAN_TILE) + 1; }
 void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st) {
@@ -1494,7 +1485,7 @@ void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st) 
     hipLaunchKernelGGL((k_exscan<1>), dim3(grid), dim3(1024), 0, st, in, out, n, tmp);
 }
 
-void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const KhSeg* segs, u32 nseg,
+void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const u32* bucket_nb,
                            u32 nbuckets, int k, void* out_keys, u32* out_counts, KhLookback lb,
                            u32 ci, u32 cx, u32 cs, hipStream_t st) {
     if (!nbuckets) return;
@@ -1503,12 +1494,12 @@ void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const KhS
     if (W == 1) {
         allow_lds(k_bucket_sort_rle<1>, lds);
         hipLaunchKernelGGL((k_bucket_sort_rle<1>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
-                           reinterpret_cast<const KmerKey<1>*>(part), bstart, segs, nseg, cap, k,
+                           reinterpret_cast<const KmerKey<1>*>(part), bstart, bucket_nb, cap, k,
                            reinterpret_cast<KmerKey<1>*>(out_keys), out_counts, lb, ci, cx, cs);
     } else {
         allow_lds(k_bucket_sort_rle<2>, lds);
         hipLaunchKernelGGL((k_bucket_sort_rle<2>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
-                           reinterpret_cast<const KmerKey<2>*>(part), bstart, segs, nseg, cap, k,
+                           reinterpret_cast<const KmerKey<2>*>(part), bstart, bucket_nb, cap, k,
                            reinterpret_cast<KmerKey<2>*>(out_keys), out_counts, lb, ci, cx, cs);
     }
 }

@@ -40,10 +40,10 @@ void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, co
 void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* thist, u64* tot,
                           hipStream_t st);
 void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
-                           hipStream_t st);
+                           u32* bucket_nb, hipStream_t st);
 size_t kh_exscan_tmp_words(u64 n);
 void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st);   // out has n+1 entries
-void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const KhSeg* segs, u32 nseg,
+void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const u32* bucket_nb,
                            u32 nbuckets, int k,
                            void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
                            hipStream_t st);
