@@ -194,7 +194,7 @@ def main():
                               "frac": round(k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k1_ms else 0.0,
                               "unit": "GB/s"},
         "kernel_ms_per_step": kernel_ms,
-        "replans": st["retries"],
+        "replans": st["retries"], "order_fallbacks": st.get("order_fallbacks", 0),
         "setup_seconds": round(gen_s, 1),
     }
 

@@ -219,6 +219,7 @@ extern "C" int kh_ctx_create(int device, kh_ctx** out) {
                        a.c_str());
     }
     HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    c->dynamic_order = getenv("KHOICE_TICKETS") != nullptr;   // see KhLookback::dynamic
     *out = c;
     return KH_OK;
 }
@@ -269,12 +270,12 @@ extern "C" int kh_stats(kh_ctx* c, char* buf, size_t buflen) {
     s += t;
     snprintf(t, sizeof t,
              "\"builds\":%llu,\"bases\":%llu,\"kmers\":%llu,\"distinct\":%llu,\"setops\":%llu,"
-             "\"setop_in\":%llu,\"setop_out\":%llu,\"retries\":%llu,\"pool_bytes\":%zu,",
+             "\"setop_in\":%llu,\"setop_out\":%llu,\"retries\":%llu,\"order_fallbacks\":%llu,\"pool_bytes\":%zu,",
              (unsigned long long)c->stat.builds, (unsigned long long)c->stat.bases,
              (unsigned long long)c->stat.kmers, (unsigned long long)c->stat.distinct,
              (unsigned long long)c->stat.setops, (unsigned long long)c->stat.setop_in,
              (unsigned long long)c->stat.setop_out, (unsigned long long)c->stat.retries,
-             c->pool.total_bytes);
+             (unsigned long long)c->stat.order_fallbacks, c->pool.total_bytes);
     s += t;
     s += "\"kernels\":{";
     for (int i = 0; i < KC_COUNT; ++i) {
@@ -473,6 +474,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     lb.desc = d_lb.as<u64>();
     lb.ticket = reinterpret_cast<u32*>(d_lb.as<u64>() + nb_total);
     lb.err = lb.ticket + 1;
+    lb.dynamic = c->dynamic_order ? 1u : 0u;
     HIPCHK(hipMemsetAsync(d_lb.b->p, 0, 8 * (u64)nb_total + 64, st));
 #ifdef KH_STAMPS
     Tmp d_stamps;
@@ -505,7 +507,13 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     HIPCHK(hipStreamSynchronize(st));
     if (g_trace) g_t_build_synced = now_ms();
     const u32 err = reinterpret_cast<const u32*>(&desc[nb_total])[1];
-    if (err & KH_ERR_SPIN_TIMEOUT) return kh_fail(KH_E_INTERNAL, "look-back spin timed out in bucket sort");
+    if (err & KH_ERR_SPIN_TIMEOUT) {
+        if (c->dynamic_order) return kh_fail(KH_E_INTERNAL, "look-back spin timed out in bucket sort");
+        c->dynamic_order = true;          // index order did not hold: tickets from now on
+        c->stat.order_fallbacks++;
+        *capacity_hit = true;             // same batch again (the caller's re-plan loop)
+        return KH_OK;
+    }
     if (err & KH_ERR_CAPACITY) { *capacity_hit = true; return KH_OK; }
     c->stat.kmers += nvalid;
 
@@ -695,6 +703,7 @@ static int setop_launch(SetopJob& j) {
     lb.desc = reinterpret_cast<u64*>(j.d_lb->p);
     lb.ticket = reinterpret_cast<u32*>(lb.desc + j.nranges);
     lb.err = lb.ticket + 1;
+    lb.dynamic = c->dynamic_order ? 1u : 0u;
     unsigned long long* d_hist = j.hist ? reinterpret_cast<unsigned long long*>(lb.desc + j.nranges + 8) : nullptr;
 #ifdef KH_STAMPS
     Tmp d_stamps;
@@ -730,7 +739,14 @@ static int setop_finish(SetopJob& j, kh_set** out) {
     }
     for (int attempt = 0; attempt < 8; ++attempt) {
         const u32 err = reinterpret_cast<const u32*>(&j.tail[1])[1];
-        if (err & KH_ERR_SPIN_TIMEOUT) return kh_fail(KH_E_INTERNAL, "look-back spin timed out in set operation");
+        if (err & KH_ERR_SPIN_TIMEOUT) {
+            if (c->dynamic_order) return kh_fail(KH_E_INTERNAL, "look-back spin timed out in set operation");
+            c->dynamic_order = true;      // index order did not hold: tickets from now on
+            c->stat.order_fallbacks++;
+            KHCHK(setop_launch(j));
+            HIPCHK(hipStreamSynchronize(c->st));
+            continue;
+        }
         if (!(err & KH_ERR_CAPACITY)) {
             const u64 n = j.tail[0] & ((1ull << 62) - 1);
             buf_ref(j.okeys);

@@ -35,7 +35,7 @@ enum KernelClass {
 struct ProfEvt { int cls; hipEvent_t a, b; };
 struct Stats {
     u64 builds = 0, bases = 0, kmers = 0, distinct = 0, setops = 0, setop_in = 0, setop_out = 0,
-        retries = 0;
+        retries = 0, order_fallbacks = 0;
 };
 
 struct kh_ctx {
@@ -54,6 +54,7 @@ struct kh_ctx {
     // context object stays behind as a closed shell until its last buffer is released.
     std::atomic<long> live_bufs{0};
     bool closed = false;
+    bool dynamic_order = false;   // KhLookback::dynamic for this context's launches
     DevBuf* buf_alloc(size_t bytes);
     // pinned host staging (small read-backs and descriptor uploads must not be pageable:
     // a pageable hipMemcpyAsync waits for the stream and would serialise queued operations)

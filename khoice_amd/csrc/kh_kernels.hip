@@ -967,7 +967,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
 
     const u32 tid = threadIdx.x, nt = blockDim.x;
     distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
-    if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
+    if (tid == 0) scratch[16] = lb.dynamic ? atomicAdd(lb.ticket, 1u) : blockIdx.x;
     __syncthreads();
     const u32 q = scratch[16];
     const u32 seg_nb = bucket_nb[q];
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
     constexpr int E = (CAPC + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
     const u32 tid = threadIdx.x, nt = blockDim.x, lane = lane_id();
     distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
-    if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
+    if (tid == 0) scratch[16] = lb.dynamic ? atomicAdd(lb.ticket, 1u) : blockIdx.x;
     __syncthreads();
     const u32 q = scratch[16];
     const u64 per = (u64)nranges + 1;

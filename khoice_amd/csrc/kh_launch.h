@@ -28,6 +28,12 @@ struct KhLookback {      // workspace of one ordered single-pass launch
     u64* desc;           // [nparts] tile descriptors, zeroed before launch
     u32* ticket;         // zeroed before launch
     u32* err;            // sticky error bits
+    // Part order.  0: part = blockIdx.x, relying on workgroups being started in index order
+    // (what the hardware does; saves a device-wide atomic and its round trip at every
+    // workgroup start).  1: parts are handed out by an atomic ticket, which needs no such
+    // assumption.  The host starts with 0 and switches a context to 1 for good if a look-back
+    // ever times out (KH_ERR_SPIN_TIMEOUT), re-running the launch.
+    u32 dynamic;
 };
 enum : u32 { KH_ERR_SPIN_TIMEOUT = 1u, KH_ERR_CAPACITY = 2u };
 

@@ -462,3 +462,24 @@ def test_sets_may_outlive_their_engine():
     e2 = E.Engine(0)
     assert len(e2.build(b"ACGTACGTTTGA", 3)) > 0
     e2.close()
+
+
+def test_ticket_order_gives_the_same_sets(monkeypatch):
+    """Parts of the ordered single-pass kernels are taken in workgroup-index order by default and
+    by an atomic ticket after a look-back timeout (or with KHOICE_TICKETS=1): same results."""
+    from khoice_amd import engine as E
+    from khoice_amd import synth
+    items = synth.species_set(3, 2, 50_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    with E.Engine(0) as e1:
+        want = e1.exp1_run(seqs, group_of, 31, cs=5000, hist_len=64, want_sets=True)
+        wk = [g.download() for g in want["group_sets"]]
+        assert e1.stats()["order_fallbacks"] == 0
+    monkeypatch.setenv("KHOICE_TICKETS", "1")
+    with E.Engine(0) as e2:
+        got = e2.exp1_run(seqs, group_of, 31, cs=5000, hist_len=64, want_sets=True)
+        for (ka, ca), g in zip(wk, got["group_sets"]):
+            kb, cb = g.download()
+            assert (ka == kb).all() and (ca == cb).all()
+        assert (got["within_hist"] == want["within_hist"]).all() and (got["across_hist"] == want["across_hist"]).all()
