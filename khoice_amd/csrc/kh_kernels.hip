@@ -966,12 +966,23 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
     constexpr int E = ((W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2) + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
 
     const u32 tid = threadIdx.x, nt = blockDim.x;
+    // index order: the bucket is known at once and its bounds are fetched while the block clears
+    // its bins (the barrier the sort needs after the clear then comes after the key loads have
+    // been issued); ticket order: everything waits for the ticket
+    const bool early = lb.dynamic == 0;
+    u32 q = blockIdx.x;
+    u32 seg_nb = 0;
+    u64 lo = 0, hi = 0;
+    if (early) { seg_nb = bucket_nb[q]; lo = bstart[q]; hi = bstart[q + 1]; }
     distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
-    if (tid == 0) scratch[16] = lb.dynamic ? atomicAdd(lb.ticket, 1u) : blockIdx.x;
-    __syncthreads();
-    const u32 q = scratch[16];
-    const u32 seg_nb = bucket_nb[q];
-    const u64 lo = bstart[q], hi = bstart[q + 1];
+    if (!early) {
+        if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
+        __syncthreads();
+        q = scratch[16];
+        seg_nb = bucket_nb[q];
+        lo = bstart[q];
+        hi = bstart[q + 1];
+    }
     const u64 n64 = hi - lo;
     KH_STAMP(q, 0);
 
@@ -991,6 +1002,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
             const u32 i = (u32)e * KH_SORT_THREADS + tid;
             if (i < n) kreg[e] = part[lo + i];
         }
+        if (early) __syncthreads();   // bins cleared by every thread before the sort counts into them
 #ifdef KH_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1111,11 +1123,24 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
                              : (W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2);
     constexpr int E = (CAPC + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
     const u32 tid = threadIdx.x, nt = blockDim.x, lane = lane_id();
-    distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
-    if (tid == 0) scratch[16] = lb.dynamic ? atomicAdd(lb.ticket, 1u) : blockIdx.x;
-    __syncthreads();
-    const u32 q = scratch[16];
     const u64 per = (u64)nranges + 1;
+    // index order: the slot is known at once, so the first wave's descriptor loads are in
+    // flight while the block clears its bins; ticket order: they wait for the ticket
+    const bool early = lb.dynamic == 0;
+    u32 q = blockIdx.x;
+    u64 pre_b0 = 0, pre_b1 = 0;
+    KhSetView pre_sv{nullptr, nullptr, 0, 0, 0};
+    if (early && tid < KH_WAVE && tid < nsets) {
+        pre_b0 = bounds[tid * per + q];
+        pre_b1 = bounds[tid * per + q + 1];
+        pre_sv = sets[tid];
+    }
+    distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
+    if (!early) {
+        if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
+        __syncthreads();
+        q = scratch[16];
+    }
     KH_STAMP(q, 0);
 
     // operand slices of this slot, described in LDS while gathering:
@@ -1138,8 +1163,10 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
             const u32 g = g0 + tid;
             u64 len = 0;
             if (g < nsets) {
-                const u64 b0 = bounds[g * per + q], b1 = bounds[g * per + q + 1];
-                const KhSetView sv = sets[g];
+                const bool pre = early && g0 == 0;
+                const u64 b0 = pre ? pre_b0 : bounds[g * per + q];
+                const u64 b1 = pre ? pre_b1 : bounds[g * per + q + 1];
+                const KhSetView sv = pre ? pre_sv : sets[g];
                 sbeg[g] = b0;
                 skey[g] = reinterpret_cast<u64>(sv.keys);
                 scnt[g] = reinterpret_cast<u64>(sv.counts);
