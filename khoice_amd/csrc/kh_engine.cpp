@@ -626,6 +626,7 @@ struct SetopJob {
     u64* tail = nullptr;
     u64* pin_hist = nullptr;
     KhSetView* views = nullptr;
+    u64 lb_words() const { return (u64)nranges + 8 + (hist ? hist_len : 0); }
     ~SetopJob() {
         buf_unref(okeys); buf_unref(ocnt); buf_unref(d_views); buf_unref(d_bounds); buf_unref(d_lb);
         if (pin && c) c->pin_release(pin, pin_bytes);
@@ -685,9 +686,9 @@ static int setop_prepare(SetopJob& j) {
     return KH_OK;
 }
 
-static int setop_launch(SetopJob& j) {
+// plan: number of slots and the per-launch workspaces
+static int setop_plan(SetopJob& j) {
     kh_ctx* c = j.c;
-    hipStream_t st = c->st;
     if (j.empty) return KH_OK;
     const int nsets = (int)j.in.size();
     const u64 nr64 = std::max<u64>(1, (j.total + j.target - 1) / j.target);
@@ -696,9 +697,59 @@ static int setop_launch(SetopJob& j) {
     JOB_ALLOC(d_bounds, 8 * ((u64)j.nranges + 1) * nsets);
     // one workspace: [descriptors: nranges][control: 64 B][histogram: hist_len], zeroed by the
     // range-bounds kernel and read back (from the last descriptor on) with one copy
+    JOB_ALLOC(d_lb, 8 * j.lb_words());
+    return KH_OK;
+}
+
+static KhBoundsJob setop_bounds_job(const SetopJob& j) {
+    return KhBoundsJob{reinterpret_cast<const KhSetView*>(j.d_views->p), reinterpret_cast<u64*>(j.d_bounds->p),
+                       reinterpret_cast<u64*>(j.d_lb->p), j.lb_words(), (u32)j.in.size(), j.nranges};
+}
+
+// slot bounds of one operation (also clears its workspace)
+static int setop_bounds(SetopJob& j) {
+    kh_ctx* c = j.c;
+    if (j.empty) return KH_OK;
+    c->prof_begin(KC_RANGE_BOUNDS);
+    kh_launch_range_bounds(j.W, reinterpret_cast<KhSetView*>(j.d_views->p), (u32)j.in.size(), j.nranges, j.k,
+                           reinterpret_cast<u64*>(j.d_bounds->p), reinterpret_cast<u64*>(j.d_lb->p),
+                           j.lb_words(), c->st);
+    c->prof_end();
+    return KH_OK;
+}
+
+// slot bounds of several planned operations (same k) in ONE launch
+static int setop_bounds_batch(kh_ctx* c, std::vector<SetopJob>& jobs, Tmp& d_jobs, void** pin, size_t* pin_bytes) {
+    std::vector<KhBoundsJob> hb;
+    u64 max_threads = 0;
+    int W = 1, k = 0;
+    for (auto& j : jobs) {
+        if (j.empty || j.in.empty()) continue;
+        hb.push_back(setop_bounds_job(j));
+        max_threads = std::max<u64>(max_threads, ((u64)j.nranges + 1) * j.in.size());
+        W = j.W;
+        k = j.k;
+    }
+    if (hb.empty()) return KH_OK;
+    *pin = c->pin_alloc(sizeof(KhBoundsJob) * hb.size(), pin_bytes);
+    if (!*pin) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
+    memcpy(*pin, hb.data(), sizeof(KhBoundsJob) * hb.size());
+    TMP_ALLOC(d_jobs, c, sizeof(KhBoundsJob) * hb.size());
+    HIPCHK(hipMemcpyAsync(d_jobs.b->p, *pin, sizeof(KhBoundsJob) * hb.size(), hipMemcpyHostToDevice, c->st));
+    c->prof_begin(KC_RANGE_BOUNDS);
+    kh_launch_range_bounds_batch(W, d_jobs.as<KhBoundsJob>(), (u32)hb.size(), max_threads, k, c->st);
+    c->prof_end();
+    HIPCHK(hipGetLastError());
+    return KH_OK;
+}
+
+// the operation itself + the read-back of its tail
+static int setop_run(SetopJob& j) {
+    kh_ctx* c = j.c;
+    hipStream_t st = c->st;
+    if (j.empty) return KH_OK;
+    const int nsets = (int)j.in.size();
     const u64 hist_words = j.hist ? j.hist_len : 0;
-    const u64 lb_words = (u64)j.nranges + 8 + hist_words;
-    JOB_ALLOC(d_lb, 8 * lb_words);
     KhLookback lb;
     lb.desc = reinterpret_cast<u64*>(j.d_lb->p);
     lb.ticket = reinterpret_cast<u32*>(lb.desc + j.nranges);
@@ -711,10 +762,6 @@ static int setop_launch(SetopJob& j) {
     HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * (u64)j.nranges, st));
     kh_debug_set_stamps(d_stamps.as<u64>());
 #endif
-    c->prof_begin(KC_RANGE_BOUNDS);
-    kh_launch_range_bounds(j.W, reinterpret_cast<KhSetView*>(j.d_views->p), nsets, j.nranges, j.k,
-                           reinterpret_cast<u64*>(j.d_bounds->p), lb.desc, lb_words, st);
-    c->prof_end();
     c->prof_begin(KC_SETOP);
     kh_launch_setop(j.W, j.pay, j.cap, reinterpret_cast<KhSetView*>(j.d_views->p), nsets,
                     reinterpret_cast<u64*>(j.d_bounds->p), j.nranges, j.k, j.op, j.mode, j.cs, j.okeys->p,
@@ -727,6 +774,12 @@ static int setop_launch(SetopJob& j) {
 #endif
     HIPCHK(hipMemcpyAsync(j.tail, lb.desc + (j.nranges - 1), 8 * (9 + hist_words), hipMemcpyDeviceToHost, st));
     return KH_OK;
+}
+
+static int setop_launch(SetopJob& j) {
+    KHCHK(setop_plan(j));
+    KHCHK(setop_bounds(j));
+    return setop_run(j);
 }
 
 // precondition: the stream was synchronised after setop_launch(j)
@@ -1313,9 +1366,16 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
                 continue;
             }
             r = setop_prepare(j);
-            if (r == KH_OK) r = setop_launch(j);
+            if (r == KH_OK) r = setop_plan(j);
             if (r != KH_OK) { cleanup(); return r; }
         }
+        // the slot bounds of all unions of the wave in one launch, then the unions back to back
+        Tmp d_bjobs;
+        struct PinGuard { kh_ctx* c; void* p = nullptr; size_t n = 0; ~PinGuard() { if (p) c->pin_release(p, n); } } bpin{c};
+        r = setop_bounds_batch(c, jobs, d_bjobs, &bpin.p, &bpin.n);
+        for (int g = g0; g < g1 && r == KH_OK; ++g)
+            if (!jobs[g - g0].in.empty()) r = setop_run(jobs[g - g0]);
+        if (r != KH_OK) { cleanup(); return r; }
         if (g_trace) t_unions_submitted = now_ms();
         if (hipStreamSynchronize(c->st) != hipSuccess) { cleanup(); return kh_fail(KH_E_HIP, "stream sync failed"); }
         if (g_trace) t_unions_synced = now_ms();

@@ -1090,6 +1090,28 @@ __global__ void k_range_bounds(const KhSetView* __restrict__ sets, u32 nsets, u3
     bounds[idx] = lo;
 }
 
+// the same for several independent set operations in one launch (blockIdx.y = operation): the
+// group unions of one wave are planned together, and ten latency-bound little launches become one
+template <int W>
+__global__ void k_range_bounds_batch(const KhBoundsJob* __restrict__ jobs, int k) {
+    const KhBoundsJob jb = jobs[blockIdx.y];
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (u64 i = idx; i < jb.zero_words; i += (u64)gridDim.x * blockDim.x) jb.zero[i] = 0;
+    const u64 per = (u64)jb.nranges + 1;
+    if (idx >= per * jb.nsets) return;
+    const u32 g = (u32)(idx / per), r = (u32)(idx % per);
+    const KhSetView sv = jb.sets[g];
+    const KmerKey<W>* keys = reinterpret_cast<const KmerKey<W>*>(sv.keys);
+    u64 lo = 0, hi = sv.n;
+    if (r == 0) hi = 0;
+    if (r >= jb.nranges) lo = hi;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (kh_slot<W>(keys[mid], k, jb.nranges) < r) lo = mid + 1; else hi = mid;
+    }
+    jb.bounds[idx] = lo;
+}
+
 __device__ __forceinline__ long long combine_counters(int mode, long long a, long long b) {
     switch (mode) {
         case KH_OC_MIN: return a < b ? a : b;
@@ -1541,6 +1563,16 @@ void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges
     else
         hipLaunchKernelGGL((k_range_bounds<2>), dim3(grid), dim3(256), 0, st, sets, nsets, nranges,
                            k, bounds, zero, zero_words);
+}
+
+void kh_launch_range_bounds_batch(int W, const KhBoundsJob* jobs, u32 njobs, u64 max_threads, int k,
+                                  hipStream_t st) {
+    if (!njobs) return;
+    const u32 grid = (u32)((max_threads + 255) / 256);
+    if (W == 1)
+        hipLaunchKernelGGL((k_range_bounds_batch<1>), dim3(grid, njobs), dim3(256), 0, st, jobs, k);
+    else
+        hipLaunchKernelGGL((k_range_bounds_batch<2>), dim3(grid, njobs), dim3(256), 0, st, jobs, k);
 }
 
 void kh_launch_setop(int W, bool pay, u32 cap, const KhSetView* sets, u32 nsets, const u64* bounds,

@@ -24,6 +24,14 @@ struct KhSetView {    // one operand of a set operation (device-resident, sorted
     u32 pad;
 };
 
+struct KhBoundsJob {   // one set operation's share of a batched range-bounds launch
+    const KhSetView* sets;
+    u64* bounds;
+    u64* zero;          // workspace to clear (look-back descriptors, control words, histogram)
+    u64 zero_words;
+    u32 nsets, nranges;
+};
+
 struct KhLookback {      // workspace of one ordered single-pass launch
     u64* desc;           // [nparts] tile descriptors, zeroed before launch
     u32* ticket;         // zeroed before launch
@@ -55,6 +63,8 @@ void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const u32
                            hipStream_t st);
 void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges, int k,
                             u64* bounds, u64* zero, u64 zero_words, hipStream_t st);
+void kh_launch_range_bounds_batch(int W, const KhBoundsJob* jobs, u32 njobs, u64 max_threads, int k,
+                                  hipStream_t st);
 void kh_launch_setop(int W, bool pay, u32 cap, const KhSetView* sets, u32 nsets, const u64* bounds,
                      u32 nranges, int k, int op, int mode, u32 cs, void* out_keys, u32* out_counts,
                      KhLookback lb, unsigned long long* hist, u32 hist_len, hipStream_t st);
