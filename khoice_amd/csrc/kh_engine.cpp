@@ -743,37 +743,57 @@ static int setop_bounds_batch(kh_ctx* c, std::vector<SetopJob>& jobs, Tmp& d_job
     return KH_OK;
 }
 
-// the operation itself + the read-back of its tail
-static int setop_run(SetopJob& j) {
-    kh_ctx* c = j.c;
+static KhSetopJob setop_kernel_job(const SetopJob& j) {
+    u64* desc = reinterpret_cast<u64*>(j.d_lb->p);
+    return KhSetopJob{reinterpret_cast<const KhSetView*>(j.d_views->p), reinterpret_cast<const u64*>(j.d_bounds->p),
+                      j.okeys->p, reinterpret_cast<u32*>(j.ocnt->p), desc,
+                      j.hist ? reinterpret_cast<unsigned long long*>(desc + j.nranges + 8) : nullptr,
+                      (u32)j.in.size(), j.nranges};
+}
+
+// Planned operations of the same kind (same k, payload mode, operation, cs, hist_len) as launches
+// of up to KH_SETOP_BATCH each, then the read-back of every tail.
+static int setop_run_batch(kh_ctx* c, SetopJob* const* jobs, size_t njobs) {
     hipStream_t st = c->st;
-    if (j.empty) return KH_OK;
-    const int nsets = (int)j.in.size();
-    const u64 hist_words = j.hist ? j.hist_len : 0;
-    KhLookback lb;
-    lb.desc = reinterpret_cast<u64*>(j.d_lb->p);
-    lb.ticket = reinterpret_cast<u32*>(lb.desc + j.nranges);
-    lb.err = lb.ticket + 1;
-    lb.dynamic = c->dynamic_order ? 1u : 0u;
-    unsigned long long* d_hist = j.hist ? reinterpret_cast<unsigned long long*>(lb.desc + j.nranges + 8) : nullptr;
+    std::vector<SetopJob*> live;
+    for (size_t i = 0; i < njobs; ++i)
+        if (!jobs[i]->empty && !jobs[i]->in.empty()) live.push_back(jobs[i]);
+    for (size_t i0 = 0; i0 < live.size(); i0 += KH_SETOP_BATCH) {
+        const size_t m = std::min<size_t>(KH_SETOP_BATCH, live.size() - i0);
+        KhSetopBatch batch;
+        memset(&batch, 0, sizeof batch);
+        const SetopJob& f = *live[i0];
+        for (size_t i = 0; i < m; ++i) {
+            const SetopJob& j = *live[i0 + i];
+            if (j.W != f.W || j.pay != f.pay || j.cap != f.cap || j.k != f.k || j.op != f.op || j.mode != f.mode ||
+                j.cs != f.cs || j.hist_len != f.hist_len)
+                return kh_fail(KH_E_INTERNAL, "set operations of different kinds in one batch");
+            batch.job[i] = setop_kernel_job(j);
+        }
 #ifdef KH_STAMPS
-    Tmp d_stamps;
-    TMP_ALLOC(d_stamps, c, 128 * (u64)j.nranges);
-    HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * (u64)j.nranges, st));
-    kh_debug_set_stamps(d_stamps.as<u64>());
+        Tmp d_stamps;
+        TMP_ALLOC(d_stamps, c, 128 * (u64)f.nranges);
+        HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * (u64)f.nranges, st));
+        kh_debug_set_stamps(d_stamps.as<u64>());
 #endif
-    c->prof_begin(KC_SETOP);
-    kh_launch_setop(j.W, j.pay, j.cap, reinterpret_cast<KhSetView*>(j.d_views->p), nsets,
-                    reinterpret_cast<u64*>(j.d_bounds->p), j.nranges, j.k, j.op, j.mode, j.cs, j.okeys->p,
-                    reinterpret_cast<u32*>(j.ocnt->p), lb, d_hist, j.hist_len, st);
-    c->prof_end();
-    HIPCHK(hipGetLastError());
+        c->prof_begin(KC_SETOP);
+        kh_launch_setop(f.W, f.pay, f.cap, batch, (u32)m, f.k, f.op, f.mode, f.cs, f.hist_len, c->dynamic_order, st);
+        c->prof_end();
+        HIPCHK(hipGetLastError());
 #ifdef KH_STAMPS
-    report_stamps(c, "setop", d_stamps.b, j.nranges);
-    kh_debug_set_stamps(nullptr);
+        report_stamps(c, "setop", d_stamps.b, f.nranges);
+        kh_debug_set_stamps(nullptr);
 #endif
-    HIPCHK(hipMemcpyAsync(j.tail, lb.desc + (j.nranges - 1), 8 * (9 + hist_words), hipMemcpyDeviceToHost, st));
+    }
+    for (SetopJob* j : live)
+        HIPCHK(hipMemcpyAsync(j->tail, reinterpret_cast<u64*>(j->d_lb->p) + (j->nranges - 1),
+                              8 * (9 + (j->hist ? j->hist_len : 0)), hipMemcpyDeviceToHost, st));
     return KH_OK;
+}
+
+static int setop_run(SetopJob& j) {
+    SetopJob* one = &j;
+    return setop_run_batch(j.c, &one, 1);
 }
 
 static int setop_launch(SetopJob& j) {
@@ -1373,8 +1393,11 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
         Tmp d_bjobs;
         struct PinGuard { kh_ctx* c; void* p = nullptr; size_t n = 0; ~PinGuard() { if (p) c->pin_release(p, n); } } bpin{c};
         r = setop_bounds_batch(c, jobs, d_bjobs, &bpin.p, &bpin.n);
-        for (int g = g0; g < g1 && r == KH_OK; ++g)
-            if (!jobs[g - g0].in.empty()) r = setop_run(jobs[g - g0]);
+        if (r == KH_OK) {
+            std::vector<SetopJob*> run;
+            for (auto& j : jobs) run.push_back(&j);
+            r = setop_run_batch(c, run.data(), run.size());
+        }
         if (r != KH_OK) { cleanup(); return r; }
         if (g_trace) t_unions_submitted = now_ms();
         if (hipStreamSynchronize(c->st) != hipSuccess) { cleanup(); return kh_fail(KH_E_HIP, "stream sync failed"); }

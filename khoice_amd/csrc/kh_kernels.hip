@@ -1128,10 +1128,23 @@ __device__ __forceinline__ long long combine_counters(int mode, long long a, lon
 // exp_type_1.smk:182,250).  PAY=true: payload = counter | (operand index > 0) << 31.
 template <int W, bool PAY>
 __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_setop(
-    const KhSetView* __restrict__ sets, u32 nsets, const u64* __restrict__ bounds, u32 nranges,
-    u32 cap, int k, int op, int mode, u32 cs, KmerKey<W>* __restrict__ out_keys,
-    u32* __restrict__ out_counts, KhLookback lb, unsigned long long* __restrict__ hist,
-    u32 hist_len) {
+    const KhSetopBatch batch, u32 cap, int k, int op, int mode, u32 cs, u32 hist_len, u32 dynamic) {
+    // this workgroup's operation (blockIdx.y) and slot (blockIdx.x, or a ticket); the grid is as
+    // wide as the largest operation of the batch
+    const KhSetopJob& jb = batch.job[blockIdx.y];
+    const u32 nranges = jb.nranges;
+    if (blockIdx.x >= nranges) return;
+    const KhSetView* __restrict__ sets = jb.sets;
+    const u32 nsets = jb.nsets;
+    const u64* __restrict__ bounds = jb.bounds;
+    KmerKey<W>* __restrict__ out_keys = reinterpret_cast<KmerKey<W>*>(jb.out_keys);
+    u32* __restrict__ out_counts = jb.out_counts;
+    unsigned long long* __restrict__ hist = jb.hist;
+    KhLookback lb;
+    lb.desc = jb.desc;
+    lb.ticket = reinterpret_cast<u32*>(jb.desc + nranges);
+    lb.err = lb.ticket + 1;
+    lb.dynamic = dynamic;
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     const SortLds L{lds_raw, cap, W, PAY};
     KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
@@ -1575,18 +1588,17 @@ void kh_launch_range_bounds_batch(int W, const KhBoundsJob* jobs, u32 njobs, u64
         hipLaunchKernelGGL((k_range_bounds_batch<2>), dim3(grid, njobs), dim3(256), 0, st, jobs, k);
 }
 
-void kh_launch_setop(int W, bool pay, u32 cap, const KhSetView* sets, u32 nsets, const u64* bounds,
-                     u32 nranges, int k, int op, int mode, u32 cs, void* out_keys, u32* out_counts,
-                     KhLookback lb, unsigned long long* hist, u32 hist_len, hipStream_t st) {
-    if (!nranges) return;
+void kh_launch_setop(int W, bool pay, u32 cap, const KhSetopBatch& batch, u32 njobs, int k, int op, int mode,
+                     u32 cs, u32 hist_len, bool dynamic_order, hipStream_t st) {
+    u32 width = 0;
+    for (u32 i = 0; i < njobs; ++i) width = std::max(width, batch.job[i].nranges);
+    if (!njobs || !width) return;
     const size_t lds = kh_sort_lds_bytes(W, cap, pay);
 #define KH_SO(WW, PP)                                                                            \
     do {                                                                                         \
         allow_lds(k_setop<WW, PP>, lds);                                                         \
-        hipLaunchKernelGGL((k_setop<WW, PP>), dim3(nranges), dim3(KH_SORT_THREADS), lds, st,     \
-                           sets, nsets, bounds, nranges, cap, k, op, mode, cs,                   \
-                           reinterpret_cast<KmerKey<WW>*>(out_keys), out_counts, lb, hist,       \
-                           hist_len);                                                            \
+        hipLaunchKernelGGL((k_setop<WW, PP>), dim3(width, njobs), dim3(KH_SORT_THREADS), lds, st, \
+                           batch, cap, k, op, mode, cs, hist_len, dynamic_order ? 1u : 0u);      \
     } while (0)
     if (W == 1) { if (pay) KH_SO(1, true); else KH_SO(1, false); }
     else        { if (pay) KH_SO(2, true); else KH_SO(2, false); }

@@ -32,6 +32,21 @@ struct KhBoundsJob {   // one set operation's share of a batched range-bounds la
     u32 nsets, nranges;
 };
 
+// Several independent set operations of the same kind (W, payload mode, operation, cs) run as ONE
+// launch: blockIdx.y picks the operation from this table, which travels in the kernel arguments
+// (scalar loads, no extra global round trip in front of a workgroup's first useful load).
+constexpr int KH_SETOP_BATCH = 16;
+struct KhSetopJob {
+    const KhSetView* sets;
+    const u64* bounds;
+    void* out_keys;
+    u32* out_counts;
+    u64* desc;                  // look-back workspace: [nranges] descriptors, ticket, err, fullest
+    unsigned long long* hist;   // nullptr: no fused histogram
+    u32 nsets, nranges;
+};
+struct KhSetopBatch { KhSetopJob job[KH_SETOP_BATCH]; };
+
 struct KhLookback {      // workspace of one ordered single-pass launch
     u64* desc;           // [nparts] tile descriptors, zeroed before launch
     u32* ticket;         // zeroed before launch
@@ -65,9 +80,8 @@ void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges
                             u64* bounds, u64* zero, u64 zero_words, hipStream_t st);
 void kh_launch_range_bounds_batch(int W, const KhBoundsJob* jobs, u32 njobs, u64 max_threads, int k,
                                   hipStream_t st);
-void kh_launch_setop(int W, bool pay, u32 cap, const KhSetView* sets, u32 nsets, const u64* bounds,
-                     u32 nranges, int k, int op, int mode, u32 cs, void* out_keys, u32* out_counts,
-                     KhLookback lb, unsigned long long* hist, u32 hist_len, hipStream_t st);
+void kh_launch_setop(int W, bool pay, u32 cap, const KhSetopBatch& batch, u32 njobs, int k, int op, int mode,
+                     u32 cs, u32 hist_len, bool dynamic_order, hipStream_t st);
 void kh_launch_histogram(const u32* counts, u64 n, unsigned long long* hist, u32 hist_len,
                          hipStream_t st);
 void kh_launch_unmix(int W, const void* in, void* out, u64 n, int k, hipStream_t st);
