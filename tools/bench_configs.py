@@ -2,7 +2,7 @@
 """Throughput of the single-GPU BASELINE.json configs next to bench.py's headline:
 
   cfg2  5 species x 5 genomes x 5 Mbp, k = 31: K1 build per genome (one call each) and batched
-        (one call for all 25), K4 histogram, against the C restatement on the host cores
+        (one call for all 25), K4 histogram (the CPU baseline lives in bench.py alone)
   cfg3  10 species x 10 genomes x 5 Mbp, k in {15, 21, 27, 31, 41}: fused within-group occurrence
         (steps 1-4 of exp_type_1.smk, `kh_exp1_run` without the across-group step)
 
@@ -37,7 +37,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--length", type=int, default=5_000_000)
-    ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
     import torch
     from khoice_amd import engine as E
@@ -63,16 +62,6 @@ def main():
             "k1_per_genome_ms_total": round(1e3 * t_single, 3),
             "k1_per_genome_distinct_per_s": round(distinct / t_single, 1),
             "k4_histogram_ms": round(1e3 * t_hist, 4), "k4_counters": len(u)}
-    if not a.no_cpu:
-        from oracle import c_oracle as CO
-        texts = [t for s, _, t in items if s == 1]
-        t0 = time.perf_counter()
-        dbs = [CO.count(t, 31) for t in texts]
-        dt = time.perf_counter() - t0
-        cfg2["cpu_port_k1"] = {"distinct_per_s": round(sum(len(d) for d in dbs) / dt, 1), "cores": 1,
-                               "sample": "species 1 (5 genomes), oracle/kh_oracle.c kho_count, one thread"}
-        ok = all((d.arrays()[0] == s.download_sorted()[0]).all() for d, s in zip(dbs, sets[:5]))
-        cfg2["cpu_port_k1"]["keys_equal_to_gpu"] = bool(ok)
     out["cfg2"] = cfg2
     del sets, u, dev
     eng.trim()
