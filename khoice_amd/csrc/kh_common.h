@@ -134,6 +134,7 @@ constexpr int KH_SORT_CAP_W2 = 2048;
 constexpr int KH_SORT_CAP_PAY_W1 = 4096;    // capacity with a 32-bit payload per key
 constexpr int KH_SORT_CAP_PAY_W2 = 2048;
 constexpr int KH_SORT_THREADS = 512;
+constexpr int KH_SORT_NW = KH_SORT_THREADS / 64;   // waves per sort workgroup
 constexpr int KH_SORT_WAVES_PER_SIMD = 4;   // 2 workgroups of 8 waves per CU (3 per CU measured slower: spills)
 constexpr int KH_FINE_BITS = KH_TUNE_FINE_BITS;            // fine bins of the in-LDS distribution sort
 constexpr int KH_FINE_BINS = 1 << KH_FINE_BITS;

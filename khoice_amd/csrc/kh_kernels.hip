@@ -819,24 +819,25 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
 // kept count goes through the block-wide look-back; (4) consecutive lanes write consecutive
 // outputs (coalesced).  All threads of the block must call it.
 // ------------------------------------------------------------------------------------------
-// tab[e * 8 + w] holds the number of flagged lanes of wave w in pass e (E * 8 <= 64 entries).
+// tab[e * NW + w] holds the number of flagged lanes of wave w in pass e (E * NW <= 64 entries,
+// NW = waves per workgroup).
 // One wave turns the table into its exclusive prefix (pass-major order) and stores the grand
 // total behind it; two barriers inside.
 template <int E>
 __device__ __forceinline__ void table_scan(u32* tab) {
-    static_assert(E * 8 <= KH_WAVE, "one wave scans the ballot table");
+    static_assert(E * KH_SORT_NW <= KH_WAVE, "one wave scans the ballot table");
     __syncthreads();
     if (threadIdx.x < KH_WAVE) {
         const u32 lane = threadIdx.x;
-        const u32 v = lane < (u32)E * 8 ? tab[lane] : 0u;
+        const u32 v = lane < (u32)E * KH_SORT_NW ? tab[lane] : 0u;
         u32 incl = v;
 #pragma unroll
         for (int off = 1; off < KH_WAVE; off <<= 1) {
             const u32 u = __shfl_up(incl, off);
             if (lane >= (u32)off) incl += u;
         }
-        if (lane < (u32)E * 8) tab[lane] = incl - v;
-        if (lane == KH_WAVE - 1) tab[E * 8] = incl;
+        if (lane < (u32)E * KH_SORT_NW) tab[lane] = incl - v;
+        if (lane == KH_WAVE - 1) tab[E * KH_SORT_NW] = incl;
     }
     __syncthreads();
 }
@@ -865,13 +866,13 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
             const u32 i = (u32)e * NT + tid;
             const bool head = (i < n) && (i == 0 || !key_eq(cur[e], prv[e]));
             const u64 bal = __ballot(head);
-            if (lane == 0) tab[e * 8 + wid] = (u32)__popcll(bal);
+            if (lane == 0) tab[e * KH_SORT_NW + wid] = (u32)__popcll(bal);
             lr[e] = (u32)__popcll(bal & lt_mask);
             flags |= head ? (1u << e) : 0u;
         }
     }
     table_scan<E>(tab);
-    const u32 d = tab[E * 8];
+    const u32 d = tab[E * KH_SORT_NW];
     // when no run can be dropped the slot's output count is already known: publish it now so
     // that it is visible to the successors by the time they look back
     if (all_kept && q != 0 && tid == 0) lb_store(&lb.desc[q], KH_LB_AGG | (u64)d);
@@ -880,7 +881,7 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
         // rank is already known, so the run table and the second ranking are skipped
         u32 base[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) base[e] = tab[e * 8 + wid] + lr[e];
+        for (int e = 0; e < E; ++e) base[e] = tab[e * KH_SORT_NW + wid] + lr[e];
         const u64 ob = lookback_block(lb.desc, q, (u64)d, lb.err, scratch);
 #pragma unroll
         for (int e = 0; e < E; ++e)
@@ -889,7 +890,7 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
     }
 #pragma unroll
     for (int e = 0; e < E; ++e)
-        if (flags & (1u << e)) hstart[tab[e * 8 + wid] + lr[e]] = (u16)((u32)e * NT + tid);
+        if (flags & (1u << e)) hstart[tab[e * KH_SORT_NW + wid] + lr[e]] = (u16)((u32)e * NT + tid);
     if (tid == 0) hstart[d] = (u16)n;
     __syncthreads();
     KH_STAMP(q, 6);
@@ -919,13 +920,13 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
         const u32 r = (u32)e * NT + tid;
         cnt[e] = (r < d) ? eval((u32)hstart[r], (u32)hstart[r + 1]) : 0u;
         const u64 bal = __ballot(cnt[e] != 0);
-        if (lane == 0) tab[e * 8 + wid] = (u32)__popcll(bal);
+        if (lane == 0) tab[e * KH_SORT_NW + wid] = (u32)__popcll(bal);
         lr[e] = (u32)__popcll(bal & lt_mask);
     }
     table_scan<E>(tab);
-    const u32 kept = tab[E * 8];
+    const u32 kept = tab[E * KH_SORT_NW];
 #pragma unroll
-    for (int e = 0; e < E; ++e) lr[e] += tab[e * 8 + wid];
+    for (int e = 0; e < E; ++e) lr[e] += tab[e * KH_SORT_NW + wid];
     // ---- (3) slot prefix
     const u64 obase = lookback_block(lb.desc, q, (u64)kept, lb.err, scratch);
     KH_STAMP(q, 7);
