@@ -63,7 +63,9 @@ def build_library(force: bool = False) -> str:
             _run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
                   "-I", os.path.join(ROOT, "include"), "-c", path, "-o", obj])
     if force or _newer(LIB, objs):
-        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"])
+        # --no-undefined: a launcher declared in kh_launch.h but not defined must fail the build,
+        # not the first dlopen on the GPU box
+        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,--no-undefined", "-o", LIB] + objs + ["-lz"])
     return LIB
 
 

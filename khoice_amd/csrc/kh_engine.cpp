@@ -451,6 +451,36 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     HIPCHK(hipMemcpyAsync(d_segs.b->p, segs.data(), sizeof(KhSeg) * nseq, hipMemcpyHostToDevice, st));
     if (ntiles)
         HIPCHK(hipMemcpyAsync(d_tiles.b->p, tiles.data(), sizeof(KhTile) * ntiles, hipMemcpyHostToDevice, st));
+    // Start order of pass C (KhBucketWork): buckets of up to 64 consecutive segments are
+    // interleaved (bucket 0 of each, bucket 1 of each, ...), every segment writes into its own
+    // output region [out_base, out_base + npos) and runs its own look-back chain.
+    struct Pin {
+        kh_ctx* c; void* p = nullptr; size_t bytes = 0;
+        ~Pin() { if (p) c->pin_release(p, bytes); }
+    } plan_pin{c};
+    plan_pin.p = c->pin_alloc(4 * (size_t)nb_total + 8 * (size_t)nseq, &plan_pin.bytes);
+    if (!plan_pin.p) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
+    u64* h_out_base = static_cast<u64*>(plan_pin.p);
+    u32* h_rank = reinterpret_cast<u32*>(h_out_base + nseq);
+    {
+        u64 ob = 0;
+        u32 next = 0;
+        for (int i = 0; i < nseq; ++i) { h_out_base[i] = ob; ob += segs[i].npos; }
+        for (int s0 = 0; s0 < nseq; s0 += 64) {
+            const int s1 = std::min(nseq, s0 + 64);
+            u32 deepest = 0;
+            for (int i = s0; i < s1; ++i) deepest = std::max(deepest, segs[i].nbuckets);
+            for (u32 b = 0; b < deepest; ++b)
+                for (int i = s0; i < s1; ++i)
+                    if (b < segs[i].nbuckets) h_rank[segs[i].bucket_base + b] = next++;
+        }
+    }
+    Tmp d_plan, d_work;
+    TMP_ALLOC(d_plan, c, 4 * (size_t)nb_total + 8 * (size_t)nseq);
+    TMP_ALLOC(d_work, c, sizeof(KhBucketWork) * (size_t)nb_total);
+    HIPCHK(hipMemcpyAsync(d_plan.b->p, plan_pin.p, 4 * (size_t)nb_total + 8 * (size_t)nseq, hipMemcpyHostToDevice, st));
+    const u64* d_out_base = d_plan.as<u64>();
+    const u32* d_rank = reinterpret_cast<const u32*>(d_out_base + nseq);
     c->prof_end();
 
     // ---- pass A, bucket plan, pass B
@@ -461,8 +491,8 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     c->prof_begin(KC_BUCKET_PLAN);
     kh_launch_col_totals(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_tot.as<u64>(), st);
     kh_launch_exscan(d_tot.as<u64>(), d_bstart.as<u64>(), nb_total, d_scan.as<u64>(), st);
-    kh_launch_col_offsets(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(),
-                          d_tot.as<u32>() /* free after the scan */, st);
+    kh_launch_col_offsets(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(), d_rank,
+                          d_out_base, d_work.as<KhBucketWork>(), st);
     c->prof_end();
     c->prof_begin(KC_EXTRACT_SCATTER);
     kh_launch_extract(W, true, d_seq.as<u8>(), d_segs.as<KhSeg>(), d_tiles.as<KhTile>(), ntiles,
@@ -483,7 +513,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     kh_debug_set_stamps(d_stamps.as<u64>());
 #endif
     c->prof_begin(KC_BUCKET_SORT);
-    kh_launch_bucket_sort(W, d_part.b->p, d_bstart.as<u64>(), d_tot.as<u32>(), nb_total, k, okeys->p,
+    kh_launch_bucket_sort(W, d_part.b->p, d_work.as<KhBucketWork>(), nb_total, k, okeys->p,
                           ocnt ? reinterpret_cast<u32*>(ocnt->p) : nullptr, lb, ci, cx, cs, st);
     c->prof_end();
     HIPCHK(hipGetLastError());
@@ -494,10 +524,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
 
     // ---- read back set boundaries
     if (g_trace) g_t_build_submitted = now_ms();
-    struct Pin {
-        kh_ctx* c; void* p = nullptr; size_t bytes = 0;
-        ~Pin() { if (p) c->pin_release(p, bytes); }
-    } pin{c};
+    Pin pin{c};
     pin.p = c->pin_alloc(8 * (size_t)nb_total + 64 + 8, &pin.bytes);
     if (!pin.p) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
     u64* desc = static_cast<u64*>(pin.p);
@@ -517,15 +544,12 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     if (err & KH_ERR_CAPACITY) { *capacity_hit = true; return KH_OK; }
     c->stat.kmers += nvalid;
 
-    u64 prev = 0;
-    for (int i = 0; i < nseq; ++i) {
-        const u64 incl = desc[segs[i].bucket_base + segs[i].nbuckets - 1] & ((1ull << 62) - 1);
-        const u64 n = incl - prev;
+    for (int i = 0; i < nseq; ++i) {   // a segment's chain ends with its inclusive total
+        const u64 n = desc[segs[i].bucket_base + segs[i].nbuckets - 1] & ((1ull << 62) - 1);
         buf_ref(okeys);
         if (ocnt) buf_ref(ocnt);
-        out_sets[i] = make_set(k, n, okeys, prev * kb, ocnt, prev * 4, 1, cs);
+        out_sets[i] = make_set(k, n, okeys, h_out_base[i] * kb, ocnt, h_out_base[i] * 4, 1, cs);
         c->stat.distinct += n;
-        prev = incl;
     }
     c->stat.builds += nseq;
     return KH_OK;
@@ -772,8 +796,11 @@ static int setop_run_batch(kh_ctx* c, SetopJob* const* jobs, size_t njobs) {
         }
 #ifdef KH_STAMPS
         Tmp d_stamps;
-        TMP_ALLOC(d_stamps, c, 128 * (u64)f.nranges);
-        HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * (u64)f.nranges, st));
+        u64 stamp_parts = 0;
+        for (size_t i = 0; i < m; ++i) stamp_parts = std::max<u64>(stamp_parts, live[i0 + i]->nranges);
+        stamp_parts *= m;
+        TMP_ALLOC(d_stamps, c, 128 * stamp_parts);
+        HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * stamp_parts, st));
         kh_debug_set_stamps(d_stamps.as<u64>());
 #endif
         c->prof_begin(KC_SETOP);
@@ -781,7 +808,7 @@ static int setop_run_batch(kh_ctx* c, SetopJob* const* jobs, size_t njobs) {
         c->prof_end();
         HIPCHK(hipGetLastError());
 #ifdef KH_STAMPS
-        report_stamps(c, "setop", d_stamps.b, f.nranges);
+        report_stamps(c, "setop", d_stamps.b, stamp_parts);
         kh_debug_set_stamps(nullptr);
 #endif
     }

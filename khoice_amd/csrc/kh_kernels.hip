@@ -29,7 +29,8 @@ void kh_debug_set_stamps(u64* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kh_stamp
 #define KH_STAMP(q, idx)                                                              \
     do {                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                            \
-        if (threadIdx.x == 0 && g_kh_stamps) g_kh_stamps[(u64)(q) * 16 + (idx)] = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0 && g_kh_stamps)                                          \
+            g_kh_stamps[((u64)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (idx)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                            \
     } while (0)
 #else
@@ -381,14 +382,16 @@ __global__ void k_col_totals(const KhSeg* __restrict__ segs, const u32* __restri
 }
 // turn per-tile counts into per-tile write cursors, relative to the segment's first bucket
 __global__ void k_col_offsets(const KhSeg* __restrict__ segs, u32* __restrict__ thist,
-                              const u64* __restrict__ bstart, u32* __restrict__ bucket_nb) {
+                              const u64* __restrict__ bstart, const u32* __restrict__ rank,
+                              const u64* __restrict__ seg_out_base, KhBucketWork* __restrict__ work) {
     const KhSeg sg = segs[blockIdx.y];
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= sg.nbuckets) return;
-    // pass C needs, per bucket, the bucket count of its segment (the fine-bin scale): one
-    // broadcast load there instead of a search through the segment table
-    bucket_nb[sg.bucket_base + b] = sg.nbuckets;
-    u64 running = bstart[sg.bucket_base + b] - bstart[sg.bucket_base];
+    // pass C's work item of this bucket, at its place in the interleaved start order
+    const u32 gb = sg.bucket_base + b;
+    const u64 lo = bstart[gb];
+    work[rank[gb]] = KhBucketWork{lo, seg_out_base[blockIdx.y], (u32)(bstart[gb + 1] - lo), sg.nbuckets, b, gb};
+    u64 running = lo - bstart[sg.bucket_base];
     for (u32 t = 0; t < sg.ntiles; ++t) {
         const u64 at = sg.thist_base + (u64)t * sg.nbuckets + b;
         const u32 c = thist[at];
@@ -882,10 +885,13 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
         u32 base[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) base[e] = tab[e * KH_SORT_NW + wid] + lr[e];
+        KH_STAMP(q, 6);
         const u64 ob = lookback_block(lb.desc, q, (u64)d, lb.err, scratch);
+        KH_STAMP(q, 7);
 #pragma unroll
         for (int e = 0; e < E; ++e)
             if (flags & (1u << e)) sink(ob + base[e], cur[e], 1u);
+        KH_STAMP(q, 8);
         return;
     }
 #pragma unroll
@@ -906,11 +912,13 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
 #pragma unroll
         for (int e = 0; e < E; ++e) cur[e] = s[h0[e]];
         const u64 ob = lookback_block(lb.desc, q, (u64)d, lb.err, scratch);
+        KH_STAMP(q, 7);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const u32 r = (u32)e * NT + tid;
             if (r < d) sink(ob + r, cur[e], eval(h0[e], h1[e]));
         }
+        KH_STAMP(q, 8);
         return;
     }
     // ---- (2) counters of the runs, kept runs ranked
@@ -952,9 +960,9 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
 // raises KH_ERR_CAPACITY (the host then re-plans the batch with more buckets).
 template <int W>
 __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_bucket_sort_rle(
-    const KmerKey<W>* __restrict__ part, const u64* __restrict__ bstart,
-    const u32* __restrict__ bucket_nb, u32 cap, int k, KmerKey<W>* __restrict__ out_keys,
-    u32* __restrict__ out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs) {
+    const KmerKey<W>* __restrict__ part, const KhBucketWork* __restrict__ work, u32 cap, int k,
+    KmerKey<W>* __restrict__ out_keys, u32* __restrict__ out_counts, KhLookback lb, u32 ci, u32 cx,
+    u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     const SortLds L{lds_raw, cap, W, false};
     KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
@@ -971,20 +979,22 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
     // its bins (the barrier the sort needs after the clear then comes after the key loads have
     // been issued); ticket order: everything waits for the ticket
     const bool early = lb.dynamic == 0;
-    u32 q = blockIdx.x;
-    u32 seg_nb = 0;
-    u64 lo = 0, hi = 0;
-    if (early) { seg_nb = bucket_nb[q]; lo = bstart[q]; hi = bstart[q + 1]; }
+    KhBucketWork wk{0, 0, 0, 0, 0, 0};
+    if (early) wk = work[blockIdx.x];
     distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
     if (!early) {
         if (tid == 0) scratch[16] = atomicAdd(lb.ticket, 1u);
         __syncthreads();
-        q = scratch[16];
-        seg_nb = bucket_nb[q];
-        lo = bstart[q];
-        hi = bstart[q + 1];
+        wk = work[scratch[16]];
     }
-    const u64 n64 = hi - lo;
+    const u32 seg_nb = wk.nb;
+    const u64 lo = wk.lo;
+    const u64 n64 = wk.n;
+    // the segment's own chain: descriptors [gb - b, ...), this bucket is its part number b
+    lb.desc += wk.gb - wk.b;
+    const u32 q = wk.b;
+    out_keys += wk.out_base;
+    if (out_counts) out_counts += wk.out_base;
     KH_STAMP(q, 0);
 
     auto sink = [&](u64 o, const KmerKey<W>& key, u32 c) {
@@ -1536,10 +1546,10 @@ void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* th
                        thist, tot);
 }
 void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
-                           u32* bucket_nb, hipStream_t st) {
+                           const u32* rank, const u64* seg_out_base, KhBucketWork* work, hipStream_t st) {
     if (!nseg || !max_nb) return;
     hipLaunchKernelGGL(k_col_offsets, dim3((max_nb + 255) / 256, nseg), dim3(256), 0, st, segs,
-                       thist, bstart, bucket_nb);
+                       thist, bstart, rank, seg_out_base, work);
 }
 size_t kh_exscan_tmp_words(u64 n) { return (size_t)((n + KH_SCAN_TILE - 1) / KH_SCAN_TILE) + 1; }
 void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st) {
@@ -1548,7 +1558,7 @@ void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st) 
     hipLaunchKernelGGL((k_exscan<1>), dim3(grid), dim3(1024), 0, st, in, out, n, tmp);
 }
 
-void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const u32* bucket_nb,
+void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
                            u32 nbuckets, int k, void* out_keys, u32* out_counts, KhLookback lb,
                            u32 ci, u32 cx, u32 cs, hipStream_t st) {
     if (!nbuckets) return;
@@ -1557,12 +1567,12 @@ void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const u32
     if (W == 1) {
         allow_lds(k_bucket_sort_rle<1>, lds);
         hipLaunchKernelGGL((k_bucket_sort_rle<1>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
-                           reinterpret_cast<const KmerKey<1>*>(part), bstart, bucket_nb, cap, k,
+                           reinterpret_cast<const KmerKey<1>*>(part), work, cap, k,
                            reinterpret_cast<KmerKey<1>*>(out_keys), out_counts, lb, ci, cx, cs);
     } else {
         allow_lds(k_bucket_sort_rle<2>, lds);
         hipLaunchKernelGGL((k_bucket_sort_rle<2>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
-                           reinterpret_cast<const KmerKey<2>*>(part), bstart, bucket_nb, cap, k,
+                           reinterpret_cast<const KmerKey<2>*>(part), work, cap, k,
                            reinterpret_cast<KmerKey<2>*>(out_keys), out_counts, lb, ci, cx, cs);
     }
 }

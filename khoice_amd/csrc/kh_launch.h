@@ -16,6 +16,21 @@ struct KhSeg {
 };
 struct KhTile { u32 seg; u32 tile_in_seg; };
 
+// What one pass-C workgroup needs, in the order the workgroups are started (written by
+// k_col_offsets).  Buckets of different segments are INTERLEAVED in that order and every
+// segment has its own look-back chain and output region: a workgroup's chain predecessor was
+// started (number of interleaved segments) workgroups earlier, so its aggregate is almost
+// always published by the time it is looked at (the single chain of before spent a quarter of a
+// workgroup's life waiting for the slowest of its 512 concurrent predecessors).
+struct KhBucketWork {
+    u64 lo;         // first key of the bucket in the partition array
+    u64 out_base;   // first output record of the bucket's segment
+    u32 n;          // keys in the bucket
+    u32 nb;         // buckets of the segment (fine-bin scale)
+    u32 b;          // index of the bucket inside its segment = index in the segment's chain
+    u32 gb;         // global bucket index (segment's chain starts at gb - b)
+};
+
 struct KhSetView {    // one operand of a set operation (device-resident, sorted by mixed key)
     const void* keys;
     const u32* counts;   // nullptr => every counter == uniform
@@ -69,10 +84,10 @@ void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, co
 void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* thist, u64* tot,
                           hipStream_t st);
 void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
-                           u32* bucket_nb, hipStream_t st);
+                           const u32* rank, const u64* seg_out_base, KhBucketWork* work, hipStream_t st);
 size_t kh_exscan_tmp_words(u64 n);
 void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st);   // out has n+1 entries
-void kh_launch_bucket_sort(int W, const void* part, const u64* bstart, const u32* bucket_nb,
+void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
                            u32 nbuckets, int k,
                            void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
                            hipStream_t st);
