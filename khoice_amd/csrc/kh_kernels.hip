@@ -1139,12 +1139,16 @@ __device__ __forceinline__ long long combine_counters(int mode, long long a, lon
 // exp_type_1.smk:182,250).  PAY=true: payload = counter | (operand index > 0) << 31.
 template <int W, bool PAY>
 __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_setop(
-    const KhSetopBatch batch, u32 cap, int k, int op, int mode, u32 cs, u32 hist_len, u32 dynamic) {
-    // this workgroup's operation (blockIdx.y) and slot (blockIdx.x, or a ticket); the grid is as
-    // wide as the largest operation of the batch
-    const KhSetopJob& jb = batch.job[blockIdx.y];
+    const KhSetopBatch batch, u32 njobs, u32 cap, int k, int op, int mode, u32 cs, u32 hist_len,
+    u32 dynamic) {
+    // The operations of a batch are INTERLEAVED in start order (workgroup i: operation i % njobs,
+    // slot i / njobs; the grid is njobs times the widest operation): a slot's look-back
+    // predecessor was started njobs workgroups earlier and has usually published its count by
+    // the time it is needed, instead of running in lock step with its successor.
+    const u32 job = blockIdx.x % njobs, slot_idx = blockIdx.x / njobs;
+    const KhSetopJob& jb = batch.job[job];
     const u32 nranges = jb.nranges;
-    if (blockIdx.x >= nranges) return;
+    if (slot_idx >= nranges) return;
     const KhSetView* __restrict__ sets = jb.sets;
     const u32 nsets = jb.nsets;
     const u64* __restrict__ bounds = jb.bounds;
@@ -1173,7 +1177,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
     // index order: the slot is known at once, so the first wave's descriptor loads are in
     // flight while the block clears its bins; ticket order: they wait for the ticket
     const bool early = lb.dynamic == 0;
-    u32 q = blockIdx.x;
+    u32 q = slot_idx;
     u64 pre_b0 = 0, pre_b1 = 0;
     KhSetView pre_sv{nullptr, nullptr, 0, 0, 0};
     if (early && tid < KH_WAVE && tid < nsets) {
@@ -1608,8 +1612,8 @@ void kh_launch_setop(int W, bool pay, u32 cap, const KhSetopBatch& batch, u32 nj
 #define KH_SO(WW, PP)                                                                            \
     do {                                                                                         \
         allow_lds(k_setop<WW, PP>, lds);                                                         \
-        hipLaunchKernelGGL((k_setop<WW, PP>), dim3(width, njobs), dim3(KH_SORT_THREADS), lds, st, \
-                           batch, cap, k, op, mode, cs, hist_len, dynamic_order ? 1u : 0u);      \
+        hipLaunchKernelGGL((k_setop<WW, PP>), dim3(width * njobs), dim3(KH_SORT_THREADS), lds, st, \
+                           batch, njobs, cap, k, op, mode, cs, hist_len, dynamic_order ? 1u : 0u); \
     } while (0)
     if (W == 1) { if (pay) KH_SO(1, true); else KH_SO(1, false); }
     else        { if (pay) KH_SO(2, true); else KH_SO(2, false); }
