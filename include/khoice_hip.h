@@ -101,6 +101,11 @@ int kh_set_counts(kh_ctx *ctx, const kh_set *in, uint32_t value, kh_set **out);
 int kh_union_sum(kh_ctx *ctx, const kh_set *const *sets, int nsets, uint32_t cs, kh_set **out,
                  uint64_t *hist, uint32_t hist_len);
 
+/* The fused histogram alone (exp_type_1.smk:243-259 when the caller keeps no step_7 database;
+ * the merged slices of the multi-GPU exchange): same counters as kh_union_sum, no set handle. */
+int kh_union_histogram(kh_ctx *ctx, const kh_set *const *sets, int nsets, uint32_t cs,
+                       uint64_t *hist, uint32_t hist_len);
+
 /* ---------------------------------------------------------------- K5/K6: simple
  * `kmc_tools simple A B intersect OUT -ocsum`     exp_type_2.smk:363-365,479-481
  * `kmc_tools simple A B kmers_subtract OUT`       exp_type_2.smk:377-379,493-495

@@ -641,6 +641,7 @@ struct SetopJob {
     u32 cs = 0, hist_len = 0, cap = 0, nranges = 0;
     uint64_t* hist = nullptr;
     bool pay = false, empty = false;
+    bool hist_only = false;   // nobody reads the output as one array: may run as several chains
     u64 total = 0, target = 0;
     DevBuf *okeys = nullptr, *ocnt = nullptr, *d_views = nullptr, *d_bounds = nullptr, *d_lb = nullptr;
     // pinned staging, mirroring the device workspace from its last descriptor on:
@@ -679,7 +680,7 @@ static int setop_prepare(SetopJob& j) {
         j.pin_hist = j.tail + 9;
         j.views = reinterpret_cast<KhSetView*>(j.pin_hist + j.hist_len);
     }
-    j.tail[0] = j.tail[1] = j.tail[2] = 0;
+    j.tail[0] = j.tail[1] = j.tail[2] = j.tail[3] = 0;
     KhSetView* views = j.views;
     for (int g = 0; g < nsets; ++g) {
         views[g].keys = j.in[g]->n ? j.in[g]->keys_ptr() : nullptr;
@@ -767,12 +768,21 @@ static int setop_bounds_batch(kh_ctx* c, std::vector<SetopJob>& jobs, Tmp& d_job
     return KH_OK;
 }
 
-static KhSetopJob setop_kernel_job(const SetopJob& j) {
+// kernel-side description of one planned operation: one entry, or — for a histogram-only
+// operation in index order — up to KH_SETOP_BATCH chains over consecutive slot ranges
+static void setop_kernel_jobs(const SetopJob& j, std::vector<KhSetopJob>& out) {
     u64* desc = reinterpret_cast<u64*>(j.d_lb->p);
-    return KhSetopJob{reinterpret_cast<const KhSetView*>(j.d_views->p), reinterpret_cast<const u64*>(j.d_bounds->p),
-                      j.okeys->p, reinterpret_cast<u32*>(j.ocnt->p), desc,
-                      j.hist ? reinterpret_cast<unsigned long long*>(desc + j.nranges + 8) : nullptr,
-                      (u32)j.in.size(), j.nranges};
+    u32* ctl = reinterpret_cast<u32*>(desc + j.nranges);
+    u32 chains = 1;
+    if (j.hist_only && !j.c->dynamic_order) chains = std::min<u32>(KH_SETOP_BATCH, std::max<u32>(1, j.nranges / 64));
+    for (u32 ch = 0; ch < chains; ++ch) {
+        const u32 s0 = (u32)((u64)j.nranges * ch / chains), s1 = (u32)((u64)j.nranges * (ch + 1) / chains);
+        out.push_back(KhSetopJob{reinterpret_cast<const KhSetView*>(j.d_views->p),
+                                 reinterpret_cast<const u64*>(j.d_bounds->p), j.okeys->p,
+                                 reinterpret_cast<u32*>(j.ocnt->p), desc + s0, ctl,
+                                 j.hist ? reinterpret_cast<unsigned long long*>(desc + j.nranges + 8) : nullptr,
+                                 (u32)j.in.size(), j.nranges, s0, s1 - s0});
+    }
 }
 
 // Planned operations of the same kind (same k, payload mode, operation, cs, hist_len) as launches
@@ -782,22 +792,25 @@ static int setop_run_batch(kh_ctx* c, SetopJob* const* jobs, size_t njobs) {
     std::vector<SetopJob*> live;
     for (size_t i = 0; i < njobs; ++i)
         if (!jobs[i]->empty && !jobs[i]->in.empty()) live.push_back(jobs[i]);
-    for (size_t i0 = 0; i0 < live.size(); i0 += KH_SETOP_BATCH) {
-        const size_t m = std::min<size_t>(KH_SETOP_BATCH, live.size() - i0);
+    if (live.empty()) return KH_OK;
+    std::vector<KhSetopJob> entries;
+    const SetopJob& f = *live[0];
+    for (SetopJob* jp : live) {
+        const SetopJob& j = *jp;
+        if (j.W != f.W || j.pay != f.pay || j.cap != f.cap || j.k != f.k || j.op != f.op || j.mode != f.mode ||
+            j.cs != f.cs || j.hist_len != f.hist_len)
+            return kh_fail(KH_E_INTERNAL, "set operations of different kinds in one batch");
+        setop_kernel_jobs(j, entries);
+    }
+    for (size_t i0 = 0; i0 < entries.size(); i0 += KH_SETOP_BATCH) {
+        const size_t m = std::min<size_t>(KH_SETOP_BATCH, entries.size() - i0);
         KhSetopBatch batch;
         memset(&batch, 0, sizeof batch);
-        const SetopJob& f = *live[i0];
-        for (size_t i = 0; i < m; ++i) {
-            const SetopJob& j = *live[i0 + i];
-            if (j.W != f.W || j.pay != f.pay || j.cap != f.cap || j.k != f.k || j.op != f.op || j.mode != f.mode ||
-                j.cs != f.cs || j.hist_len != f.hist_len)
-                return kh_fail(KH_E_INTERNAL, "set operations of different kinds in one batch");
-            batch.job[i] = setop_kernel_job(j);
-        }
+        for (size_t i = 0; i < m; ++i) batch.job[i] = entries[i0 + i];
 #ifdef KH_STAMPS
         Tmp d_stamps;
         u64 stamp_parts = 0;
-        for (size_t i = 0; i < m; ++i) stamp_parts = std::max<u64>(stamp_parts, live[i0 + i]->nranges);
+        for (size_t i = 0; i < m; ++i) stamp_parts = std::max<u64>(stamp_parts, batch.job[i].nranges);
         stamp_parts *= m;
         TMP_ALLOC(d_stamps, c, 128 * stamp_parts);
         HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * stamp_parts, st));
@@ -833,7 +846,7 @@ static int setop_launch(SetopJob& j) {
 static int setop_finish(SetopJob& j, kh_set** out) {
     kh_ctx* c = j.c;
     if (j.empty) {
-        *out = make_set(j.k, 0, nullptr, 0, nullptr, 0, 1, j.cs);
+        if (out) *out = make_set(j.k, 0, nullptr, 0, nullptr, 0, 1, j.cs);
         if (j.hist) memset(j.hist, 0, 8 * (size_t)j.hist_len);
         return KH_OK;
     }
@@ -848,10 +861,12 @@ static int setop_finish(SetopJob& j, kh_set** out) {
             continue;
         }
         if (!(err & KH_ERR_CAPACITY)) {
-            const u64 n = j.tail[0] & ((1ull << 62) - 1);
-            buf_ref(j.okeys);
-            buf_ref(j.ocnt);
-            *out = make_set(j.k, n, j.okeys, 0, j.ocnt, 0, 1, j.cs);
+            const u64 n = j.tail[3];   // outputs of all chains (control words, u64 at byte 16)
+            if (out) {
+                buf_ref(j.okeys);
+                buf_ref(j.ocnt);
+                *out = make_set(j.k, n, j.okeys, 0, j.ocnt, 0, 1, j.cs);
+            }
             c->stat.setop_out += n;
             if (j.hist) memcpy(j.hist, j.pin_hist, 8 * (size_t)j.hist_len);
             return KH_OK;
@@ -872,6 +887,7 @@ static int run_setop(kh_ctx* c, const std::vector<const kh_set*>& in, int op, in
                      kh_set** out, uint64_t* hist, u32 hist_len) {
     SetopJob j;
     j.c = c; j.in = in; j.op = op; j.mode = mode; j.cs = cs; j.hist = hist; j.hist_len = hist_len;
+    j.hist_only = out == nullptr;   // no set wanted: the output need not be one compact array
     KHCHK(setop_prepare(j));
     KHCHK(setop_launch(j));
     HIPCHK(hipStreamSynchronize(c->st));
@@ -904,6 +920,28 @@ extern "C" int kh_union_sum(kh_ctx* c, const kh_set* const* sets, int nsets, uin
     int r = kh_union_sum(c, partial.data(), (int)partial.size(), cs, out, hist, hist_len);
     cleanup();
     return r;
+}
+
+// The histogram of a union-sum without handing the union back (steps 7+8 of experiment type 1
+// when only step_8's histogram is wanted, and the merged slices of the multi-GPU exchange):
+// every output record is still written, but not as one compact array, so the slots run as
+// independent chains.
+extern "C" int kh_union_histogram(kh_ctx* c, const kh_set* const* sets, int nsets, uint32_t cs,
+                                  uint64_t* hist, uint32_t hist_len) {
+    if (!c || !sets || !hist || nsets <= 0) return kh_fail(KH_E_ARG, "kh_union_histogram: bad argument");
+    if (hist_len < 2) return kh_fail(KH_E_ARG, "hist_len must be >= 2");
+    if (cs < 1) return kh_fail(KH_E_ARG, "cs must be >= 1");
+    HIPCHK(hipSetDevice(c->dev));
+    for (int i = 0; i < nsets; ++i)
+        if (!sets[i]) return kh_fail(KH_E_ARG, "kh_union_histogram: operand %d is NULL", i);
+    if (nsets > KH_MAX_INPUT_SETS) {   // beyond one launch's fan-in: through the general path
+        kh_set* u = nullptr;
+        KHCHK(kh_union_sum(c, sets, nsets, cs, &u, hist, hist_len));
+        kh_set_free(u);
+        return KH_OK;
+    }
+    std::vector<const kh_set*> in(sets, sets + nsets);
+    return run_setop(c, in, KH_OP_UNION, KH_OC_SUM, cs, nullptr, hist, hist_len);
 }
 
 extern "C" int kh_simple(kh_ctx* c, const kh_set* a, const kh_set* b, int op, int mode, uint32_t cs,
@@ -1445,8 +1483,11 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
     // steps 7+8 (skipped when the caller wants neither output: the multi-GPU path does them
     // after exchanging the group sets, khoice_amd/dist.py)
     if (g_trace) t_groups_done = now_ms();
-    if (across_hist || across_set) {
+    if (across_set) {
         r = kh_union_sum(c, usets.data(), ngroups, cs, &across, across_hist, hist_len);
+        if (r != KH_OK) { cleanup(); return r; }
+    } else if (across_hist) {
+        r = kh_union_histogram(c, usets.data(), ngroups, cs, across_hist, hist_len);
         if (r != KH_OK) { cleanup(); return r; }
     }
     if (g_trace)

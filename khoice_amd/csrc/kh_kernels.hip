@@ -846,7 +846,7 @@ __device__ __forceinline__ void table_scan(u32* tab) {
 }
 
 template <int W, int E, class Eval, class Sink>
-__device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab, Eval eval, Sink sink,
+__device__ u64 rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab, Eval eval, Sink sink,
                          KhLookback lb, const u32 q, u32* scratch, const bool all_kept,
                          const bool keys_only = false) {
     constexpr u32 NT = KH_SORT_THREADS;
@@ -892,7 +892,7 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
         for (int e = 0; e < E; ++e)
             if (flags & (1u << e)) sink(ob + base[e], cur[e], 1u);
         KH_STAMP(q, 8);
-        return;
+        return ob + d;
     }
 #pragma unroll
     for (int e = 0; e < E; ++e)
@@ -919,7 +919,7 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
             if (r < d) sink(ob + r, cur[e], eval(h0[e], h1[e]));
         }
         KH_STAMP(q, 8);
-        return;
+        return ob + d;
     }
     // ---- (2) counters of the runs, kept runs ranked
     u32 cnt[E];
@@ -947,6 +947,7 @@ __device__ void rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab
         }
     }
     KH_STAMP(q, 8);
+    return obase + kept;   // all outputs of the chain up to and including this part
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1157,9 +1158,10 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
     unsigned long long* __restrict__ hist = jb.hist;
     KhLookback lb;
     lb.desc = jb.desc;
-    lb.ticket = reinterpret_cast<u32*>(jb.desc + nranges);
-    lb.err = lb.ticket + 1;
+    lb.ticket = jb.ctl;
+    lb.err = jb.ctl + 1;
     lb.dynamic = dynamic;
+    const u32 slot0 = jb.slot0, nslots = jb.nslots;
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     const SortLds L{lds_raw, cap, W, PAY};
     KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
@@ -1173,16 +1175,16 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
                              : (W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2);
     constexpr int E = (CAPC + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
     const u32 tid = threadIdx.x, nt = blockDim.x, lane = lane_id();
-    const u64 per = (u64)nranges + 1;
+    const u64 per = (u64)nslots + 1;
     // index order: the slot is known at once, so the first wave's descriptor loads are in
     // flight while the block clears its bins; ticket order: they wait for the ticket
     const bool early = lb.dynamic == 0;
-    u32 q = slot_idx;
+    u32 q = slot_idx;             // part number inside this chain; the slot itself is slot0 + q
     u64 pre_b0 = 0, pre_b1 = 0;
     KhSetView pre_sv{nullptr, nullptr, 0, 0, 0};
     if (early && tid < KH_WAVE && tid < nsets) {
-        pre_b0 = bounds[tid * per + q];
-        pre_b1 = bounds[tid * per + q + 1];
+        pre_b0 = bounds[tid * per + slot0 + q];
+        pre_b1 = bounds[tid * per + slot0 + q + 1];
         pre_sv = sets[tid];
     }
     distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
@@ -1208,15 +1210,16 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
     u64* skey = reinterpret_cast<u64*>(dsc + 4 * MAXG);
     u64* scnt = reinterpret_cast<u64*>(dsc + 6 * MAXG);
     if (tid < KH_WAVE) {   // one wave scans the slice lengths, 64 operands per round
-        u64 carry = 0;
+        u64 carry = 0, chain_in = 0;
         for (u32 g0 = 0; g0 < nsets; g0 += KH_WAVE) {
             const u32 g = g0 + tid;
             u64 len = 0;
             if (g < nsets) {
                 const bool pre = early && g0 == 0;
-                const u64 b0 = pre ? pre_b0 : bounds[g * per + q];
-                const u64 b1 = pre ? pre_b1 : bounds[g * per + q + 1];
+                const u64 b0 = pre ? pre_b0 : bounds[g * per + slot0 + q];
+                const u64 b1 = pre ? pre_b1 : bounds[g * per + slot0 + q + 1];
                 const KhSetView sv = pre ? pre_sv : sets[g];
+                if (slot0) chain_in += bounds[g * per + slot0];   // inputs in front of this chain
                 sbeg[g] = b0;
                 skey[g] = reinterpret_cast<u64>(sv.keys);
                 scnt[g] = reinterpret_cast<u64>(sv.counts);
@@ -1235,10 +1238,18 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
             }
             carry += __shfl(incl, KH_WAVE - 1);
         }
-        if (tid == 0) bcast[1] = carry;
+        if (slot0) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) chain_in += __shfl_xor(chain_in, off);
+        }
+        if (tid == 0) { bcast[1] = carry; bcast[2] = chain_in; }
     }
     __syncthreads();
     const u64 n64 = bcast[1];
+    // a chain that does not start at slot 0 writes where its inputs start: no output of an
+    // earlier chain can reach that far (every output key is one of the inputs)
+    out_keys += bcast[2];
+    if (out_counts) out_counts += bcast[2];
     u32 n = 0;
     if (n64 > (u64)CAPC || n64 > (u64)cap) {
         if (tid == 0) {
@@ -1285,7 +1296,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
 #endif
     KH_STAMP(q, 1);
     distribute_sort<W, PAY, E>(kreg, preg, n, s, pay, reinterpret_cast<u32*>(hstart), tab + 128,
-                               tab + 128 + KH_FINE_BINS / 32, scratch, k, nranges, q);
+                               tab + 128 + KH_FINE_BINS / 32, scratch, k, nslots, q);
 
     // counter of run s[h0..h1) under the requested operation (0 = key dropped)
     auto eval = [&](u32 h0, u32 h1) -> u32 {
@@ -1336,7 +1347,10 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
             else atomicAdd(&hist[c < hist_len ? c : hist_len - 1], 1ull);
         }
     };
-    rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch, op == KH_OP_UNION && mode != KH_OC_DIFF);
+    const u64 chain_out = rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, q, scratch,
+                                         op == KH_OP_UNION && mode != KH_OC_DIFF);
+    if (q == nranges - 1 && tid == 0)   // the chain is complete: its outputs join the operation's total
+        atomicAdd(reinterpret_cast<unsigned long long*>(jb.ctl + 4), (unsigned long long)chain_out);
     if (hist) {
         __syncthreads();
         for (u32 c = tid >> 6; c < 16; c += nt >> 6) {      // one wave folds two counters

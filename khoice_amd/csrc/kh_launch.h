@@ -53,13 +53,20 @@ struct KhBoundsJob {   // one set operation's share of a batched range-bounds la
 constexpr int KH_SETOP_BATCH = 16;
 struct KhSetopJob {
     const KhSetView* sets;
-    const u64* bounds;
+    const u64* bounds;          // [nsets][nslots + 1] of the whole operation
     void* out_keys;
     u32* out_counts;
-    u64* desc;                  // look-back workspace: [nranges] descriptors, ticket, err, fullest
+    u64* desc;                  // this chain's look-back descriptors [nranges]
+    u32* ctl;                   // the operation's control words: ticket, err, fullest slot, pad, u64 outputs
     unsigned long long* hist;   // nullptr: no fused histogram
-    u32 nsets, nranges;
+    u32 nsets;
+    u32 nslots;                 // slots of the whole operation (the key -> slot scale)
+    u32 slot0, nranges;         // this chain covers slots [slot0, slot0 + nranges)
 };
+// An operation whose output set nobody reads as ONE array (histogram-only unions) is run as several
+// chains: consecutive slot ranges with their own look-back chain, each writing at the offset its
+// inputs start at (sum over operands of bounds[slot0]) — same bytes written, no global order to
+// wait for.  A chain adds its output count to ctl's u64 when its last slot finishes.
 struct KhSetopBatch { KhSetopJob job[KH_SETOP_BATCH]; };
 
 struct KhLookback {      // workspace of one ordered single-pass launch

@@ -103,7 +103,7 @@ class EngineOps:
         torch.cuda.synchronize(self.device)   # the collective ran on torch's stream
 
     def union_hist(self, sets, cs, hist_len):
-        return self.eng.union_sum(sets, cs, hist_len=hist_len)
+        return None, self.eng.union_histogram(sets, cs, hist_len)
 
     # -- direct-addressed occurrence table (k <= 16)
     def table_add(self, s, table_t):

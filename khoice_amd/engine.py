@@ -63,6 +63,7 @@ def load_library(path: Optional[str] = None):
         "kh_free_host": (None, [vp]),
         "kh_set_counts": (C.c_int, [vp, vp, C.c_uint32, C.POINTER(vp)]),
         "kh_union_sum": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_uint32, C.POINTER(vp), u64p, C.c_uint32]),
+        "kh_union_histogram": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_uint32, u64p, C.c_uint32]),
         "kh_simple": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_uint32, C.POINTER(vp)]),
         "kh_histogram": (C.c_int, [vp, vp, u64p, C.c_uint32]),
         "kh_histogram_file": (C.c_int, [vp, vp, C.c_uint32, C.c_char_p]),
@@ -104,7 +105,7 @@ def load_library(path: Optional[str] = None):
 ABI_SYMBOLS = [
     "kh_ctx_create", "kh_ctx_destroy", "kh_last_error", "kh_device_count", "kh_stats",
     "kh_profile_enable", "kh_stats_reset", "kh_sync", "kh_trim", "kh_build_batch", "kh_build_fasta",
-    "kh_read_fasta", "kh_free_host", "kh_set_counts", "kh_union_sum", "kh_simple", "kh_histogram",
+    "kh_read_fasta", "kh_free_host", "kh_set_counts", "kh_union_sum", "kh_union_histogram", "kh_simple", "kh_histogram",
     "kh_histogram_file", "kh_membership", "kh_confusion_row",
     "kh_table_add_set", "kh_table_histogram", "kh_dump_sorted", "kh_set_free", "kh_set_info", "kh_set_counter_max",
     "kh_set_download",
@@ -326,6 +327,14 @@ class Engine:
                                       _u64p(hist) if hist_len else None, hist_len))
         res = KmerSet(self, out.value)
         return (res, hist) if hist_len else res
+
+    def union_histogram(self, sets: Sequence[KmerSet], cs: int, hist_len: int) -> np.ndarray:
+        """hist of `kmc_tools complex (set1 + ... ) -csN` + `transform histogram` without keeping
+        the union (its slots then run as independent chains)."""
+        hist = np.zeros(hist_len, dtype=np.uint64)
+        arr = (C.c_void_p * len(sets))(*[s._h for s in sets])
+        _check(self._lib.kh_union_histogram(self._ctx, arr, len(sets), cs, _u64p(hist), hist_len))
+        return hist
 
     def simple(self, a: KmerSet, b: KmerSet, op: int, mode: str = "min", cs: int = KMC_DEFAULT_CS) -> KmerSet:
         out = C.c_void_p()

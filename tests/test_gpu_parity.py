@@ -483,3 +483,28 @@ def test_ticket_order_gives_the_same_sets(monkeypatch):
             kb, cb = g.download()
             assert (ka == kb).all() and (ca == cb).all()
         assert (got["within_hist"] == want["within_hist"]).all() and (got["across_hist"] == want["across_hist"]).all()
+
+
+@pytest.mark.parametrize("k", [21, 41])
+def test_union_histogram_chains_equal_union_sum(eng, k):
+    """kh_union_histogram runs the slots as independent chains (no compact output set): the
+    histogram and the number of output records equal kh_union_sum's; also for fan-in > 128."""
+    rng = random.Random(77 + k)
+    base = random_dna(rng, 600_000)
+    texts = []
+    for g in range(6):
+        a = rng.randrange(0, 100_000)
+        texts.append(base[a:a + 450_000] + "N" + random_dna(rng, 30_000))
+    sets = [eng.build(t.encode(), k).set_counts(1) for t in texts]
+    u = eng.union_sum(sets, 5000, hist_len=16)
+    uset, want = u if isinstance(u, tuple) else (u, None)
+    before = eng.stats()["setop_out"]
+    got = eng.union_histogram(sets, 5000, 16)
+    assert (got == want).all()
+    assert eng.stats()["setop_out"] - before == len(uset)      # every record was still produced
+    assert int(got.sum()) == len(uset)
+    many = [sets[i % 6] for i in range(140)]                  # beyond one launch's fan-in
+    _, want2 = eng.union_sum(many, 5000, hist_len=200)
+    assert (eng.union_histogram(many, 5000, 200) == want2).all()
+    empty = eng.build(b"ACG", k).set_counts(1)
+    assert int(eng.union_histogram([empty, empty], 5000, 8).sum()) == 0
