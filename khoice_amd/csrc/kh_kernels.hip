@@ -1180,12 +1180,16 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
     // flight while the block clears its bins; ticket order: they wait for the ticket
     const bool early = lb.dynamic == 0;
     u32 q = slot_idx;             // part number inside this chain; the slot itself is slot0 + q
+    // With at most 64 operands every wave describes the slot for ITSELF, lane g holding operand g
+    // (redundant loads, served by the caches): no LDS descriptors, no "wave 0 scans, everyone
+    // waits", no chain of dependent LDS reads in front of the key loads.
+    const bool wave_local = nsets <= (u32)KH_WAVE;
     u64 pre_b0 = 0, pre_b1 = 0;
     KhSetView pre_sv{nullptr, nullptr, 0, 0, 0};
-    if (early && tid < KH_WAVE && tid < nsets) {
-        pre_b0 = bounds[tid * per + slot0 + q];
-        pre_b1 = bounds[tid * per + slot0 + q + 1];
-        pre_sv = sets[tid];
+    if (early && (wave_local || tid < KH_WAVE) && lane < nsets) {
+        pre_b0 = bounds[lane * per + slot0 + q];
+        pre_b1 = bounds[lane * per + slot0 + q + 1];
+        pre_sv = sets[lane];
     }
     distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
     if (!early) {
@@ -1194,6 +1198,87 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
         q = scratch[16];
     }
     KH_STAMP(q, 0);
+
+    KmerKey<W> kreg[E];
+    u32 preg[E];
+    u32 n = 0;
+    if (wave_local) {
+        const bool have = lane < nsets;
+        if (!early && have) {
+            pre_b0 = bounds[lane * per + slot0 + q];
+            pre_b1 = bounds[lane * per + slot0 + q + 1];
+            pre_sv = sets[lane];
+        }
+        u64 chain_in = (slot0 && have) ? bounds[lane * per + slot0] : 0ull;   // inputs in front of this chain
+        const u64 len = have ? pre_b1 - pre_b0 : 0ull;
+        u64 incl = len;
+#pragma unroll
+        for (int off = 1; off < KH_WAVE; off <<= 1) {
+            const u64 u = __shfl_up(incl, off);
+            if (lane >= (u32)off) incl += u;
+        }
+        const u64 n64 = __shfl(incl, KH_WAVE - 1);
+        if (slot0) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) chain_in += __shfl_xor(chain_in, off);
+        }
+        out_keys += chain_in;
+        if (out_counts) out_counts += chain_in;
+        if (n64 > (u64)CAPC || n64 > (u64)cap) {
+            if (tid == 0) {
+                atomicOr(lb.err, KH_ERR_CAPACITY);
+                atomicMax(lb.err + 1, n64 > 0xffffffffull ? 0xffffffffu : (u32)n64);   // fullest slot seen
+            }
+        } else {
+            n = (u32)n64;
+        }
+        // operands that do not exist start "after everything"
+        const u32 soff = have ? (u32)(incl - len) : 0xffffffffu;
+        const u64 sbeg = pre_b0, skey = reinterpret_cast<u64>(pre_sv.keys), scnt = reinterpret_cast<u64>(pre_sv.counts);
+        const u32 suni = pre_sv.uniform;
+        auto lane64 = [](u64 v, u32 src) -> u64 {   // value of lane `src` (uniform), via scalar reads
+            const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, (int)src);
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), (int)src);
+            return ((u64)hi << 32) | lo;
+        };
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            kreg[e] = key_zero<W>();
+            preg[e] = 0;
+            // this wave's 64 elements of pass e are [B, B + 64): nearly always inside ONE operand
+            const u32 B = (u32)e * KH_SORT_THREADS + (tid & ~(u32)(KH_WAVE - 1));
+            const u32 i = B + lane;
+            const u32 g_lo = (u32)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(soff <= B))) - 1u;
+            const u32 g_hi = (u32)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(soff <= B + (KH_WAVE - 1)))) - 1u;
+            u32 ga = g_lo, my_soff;
+            u64 my_sbeg, my_skey, my_scnt = 0;
+            u32 my_suni = 0;
+            if (g_lo == g_hi) {
+                my_soff = (u32)__builtin_amdgcn_readlane((int)soff, (int)g_lo);
+                my_sbeg = lane64(sbeg, g_lo);
+                my_skey = lane64(skey, g_lo);
+                if (PAY) { my_scnt = lane64(scnt, g_lo); my_suni = (u32)__builtin_amdgcn_readlane((int)suni, (int)g_lo); }
+            } else {   // an operand boundary inside the 64 elements: per-lane choice
+                for (u32 gg = g_lo + 1; gg <= g_hi; ++gg)
+                    ga += ((u32)__builtin_amdgcn_readlane((int)soff, (int)gg) <= i) ? 1u : 0u;
+                my_soff = __shfl(soff, ga);
+                my_sbeg = __shfl(sbeg, ga);
+                my_skey = __shfl(skey, ga);
+                if (PAY) { my_scnt = __shfl(scnt, ga); my_suni = __shfl(suni, ga); }
+            }
+            if (i < n) {
+                const u64 idx = my_sbeg + (i - my_soff);
+                kreg[e] = reinterpret_cast<const KmerKey<W>*>(my_skey)[idx];
+                if (PAY) {
+                    const u32* cp = reinterpret_cast<const u32*>(my_scnt);
+                    u32 c = cp ? cp[idx] : my_suni;
+                    if (c > 0x7fffffffu) c = 0x7fffffffu;
+                    // binary operations tag the second operand; n-ary unions only ever sum
+                    preg[e] = c | ((nsets == 2 && ga == 1) ? 0x80000000u : 0u);
+                }
+            }
+        }
+    } else {
 
     // operand slices of this slot, described in LDS while gathering:
     //   soff[g] u32  first gathered index of operand g's slice (exclusive scan)
@@ -1250,7 +1335,6 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
     // earlier chain can reach that far (every output key is one of the inputs)
     out_keys += bcast[2];
     if (out_counts) out_counts += bcast[2];
-    u32 n = 0;
     if (n64 > (u64)CAPC || n64 > (u64)cap) {
         if (tid == 0) {
             atomicOr(lb.err, KH_ERR_CAPACITY);
@@ -1261,8 +1345,6 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
     }
     // gather straight into registers: element i of the concatenated slices belongs to the last
     // operand whose slice starts at or before i; all loads of a thread are independent
-    KmerKey<W> kreg[E];
-    u32 preg[E];
     u32 ga = 0;   // operand of this thread's current element: found once, then only advanced
     {
         u32 gb = nsets;
@@ -1288,6 +1370,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
                 preg[e] = c | ((nsets == 2 && ga == 1) ? 0x80000000u : 0u);
             }
         }
+    }
     }
     __syncthreads();   // the slice descriptors are no longer needed
     for (u32 i = tid; i < KH_LHIST_BINS; i += nt) lhist[i] = 0;
