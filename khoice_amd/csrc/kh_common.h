@@ -126,7 +126,7 @@ constexpr int KH_MAX_BUCKETS_PER_SEG = 16384;   // LDS cursor array limit (64 Ki
 #define KH_TUNE_FINE_BITS 13
 #endif
 constexpr int KH_BUCKET_MEAN_W1 = KH_TUNE_MEAN_W1;     // target keys per bucket (typical P = 4096)
-constexpr int KH_BUCKET_MEAN_W2 = 1850;
+constexpr int KH_BUCKET_MEAN_W2 = 1750;   // 7 sigma below the 2048 capacity (1850 = 4.6 sigma re-planned one 250 Mbp batch in four)
 // LDS sort capacity in keys.  Mixed keys make slot sizes Poisson-tight (mean 3400 -> sigma 58),
 // so 4096 leaves 6.5 sigma over the 3700 mean (beyond: the oversize path / a re-plan); 8 keys per thread keep the unrolled per-thread arrays in <128 VGPRs.
 constexpr int KH_SORT_CAP_W1 = 4096;
