@@ -42,6 +42,34 @@ void kh_debug_set_stamps(u64* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kh_stamp
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & (KH_WAVE - 1); }
 
+// Wave-wide inclusive scans on the DPP data path (row shifts inside the 16-lane rows, then the
+// two row broadcasts of gfx9): six dependent VALU steps of a few cycles each, where the generic
+// __shfl_up goes through ds_bpermute, i.e. pays an LDS round trip per step.  Lanes without a
+// source read 0 (bound_ctrl) or keep the 0 passed as `old` (rows masked off).
+#define KH_DPP_STEP(v, OP, ctrl, rmask, bctl) \
+    v = OP(v, (u32)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, bctl))
+__device__ __forceinline__ u32 kh_addu(u32 a, u32 b) { return a + b; }
+__device__ __forceinline__ u32 kh_maxu(u32 a, u32 b) { return a > b ? a : b; }
+__device__ __forceinline__ u32 wave_scan_add(u32 v) {
+    KH_DPP_STEP(v, kh_addu, 0x111, 0xf, true);    // row_shr:1
+    KH_DPP_STEP(v, kh_addu, 0x112, 0xf, true);    // row_shr:2
+    KH_DPP_STEP(v, kh_addu, 0x114, 0xf, true);    // row_shr:4
+    KH_DPP_STEP(v, kh_addu, 0x118, 0xf, true);    // row_shr:8
+    KH_DPP_STEP(v, kh_addu, 0x142, 0xa, false);   // row_bcast:15 into rows 1 and 3
+    KH_DPP_STEP(v, kh_addu, 0x143, 0xc, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// maximum of the wave, valid in lane 63 (callers read it from there)
+__device__ __forceinline__ u32 wave_scan_max(u32 v) {
+    KH_DPP_STEP(v, kh_maxu, 0x111, 0xf, true);
+    KH_DPP_STEP(v, kh_maxu, 0x112, 0xf, true);
+    KH_DPP_STEP(v, kh_maxu, 0x114, 0xf, true);
+    KH_DPP_STEP(v, kh_maxu, 0x118, 0xf, true);
+    KH_DPP_STEP(v, kh_maxu, 0x142, 0xa, false);
+    KH_DPP_STEP(v, kh_maxu, 0x143, 0xc, false);
+    return v;
+}
+
 // rank of this thread among flagged threads of the block (exclusive) and the block total.
 // wave_tot: LDS scratch of blockDim/64 words.  Contains two barriers.
 __device__ __forceinline__ u32 block_rank(bool flag, u32* wave_tot, u32& total) {
@@ -312,12 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
                 c[j] = (j < per && b < nb) ? sub[b] : 0u;
                 sum += c[j];
             }
-            u32 incl = sum;
-#pragma unroll
-            for (int off = 1; off < KH_WAVE; off <<= 1) {
-                const u32 v = __shfl_up(incl, off);
-                if (lane >= (u32)off) incl += v;
-            }
+            const u32 incl = wave_scan_add(sum);
             if (lane == KH_WAVE - 1) wsum[wid] = incl;
             __syncthreads();
             u32 run = incl - sum;
@@ -680,19 +703,9 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
         mx = c1 > mx ? c1 : mx;
         sum += c0 + c1;
     }
-    u32 incl = sum;
-#pragma unroll
-    for (int off = 1; off < KH_WAVE; off <<= 1) {
-        const u32 u = __shfl_up(incl, off);
-        if (lane >= (u32)off) incl += u;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const u32 o = __shfl_xor(mx, off);
-        mx = o > mx ? o : mx;
-    }
-    if (lane == KH_WAVE - 1) scratch[wid] = incl;
-    if (lane == 0) scratch[8 + wid] = mx;
+    const u32 incl = wave_scan_add(sum);
+    mx = wave_scan_max(mx);                      // the wave's maximum arrives in lane 63
+    if (lane == KH_WAVE - 1) { scratch[wid] = incl; scratch[8 + wid] = mx; }
     __syncthreads();
     u32 wbase = 0, bmax = 0;
 #pragma unroll
@@ -833,12 +846,7 @@ __device__ __forceinline__ void table_scan(u32* tab) {
     if (threadIdx.x < KH_WAVE) {
         const u32 lane = threadIdx.x;
         const u32 v = lane < (u32)E * KH_SORT_NW ? tab[lane] : 0u;
-        u32 incl = v;
-#pragma unroll
-        for (int off = 1; off < KH_WAVE; off <<= 1) {
-            const u32 u = __shfl_up(incl, off);
-            if (lane >= (u32)off) incl += u;
-        }
+        const u32 incl = wave_scan_add(v);
         if (lane < (u32)E * KH_SORT_NW) tab[lane] = incl - v;
         if (lane == KH_WAVE - 1) tab[E * KH_SORT_NW] = incl;
     }
