@@ -617,11 +617,15 @@ __device__ u64 lookback_block(u64* desc, const u32 q, const u64 mine, u32* err, 
             const u32 f = first_in_wave[w];
             if (f < 64u) { tp = w * KH_WAVE + f; break; }
         }
-        u64 v = (tid <= tp) ? (dsc & KH_LB_VALUE) : 0ull;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) wave_sum[wid] = v;
+        // aggregates in front of the nearest prefix are per-part counts (far below 2^32 for a
+        // whole wave): summed on the DPP path; the prefix itself, one 64-bit value, is added by
+        // the thread that holds it
+        const u32 small = wave_scan_add((tid < tp) ? (u32)(dsc & KH_LB_VALUE) : 0u);
+        if (lane == KH_WAVE - 1) wave_sum[wid] = small;
+        if (tid == tp) wave_sum[nw] = dsc & KH_LB_VALUE;
         __syncthreads();
         for (u32 w = 0; w < nw; ++w) excl += wave_sum[w];
+        if (tp != 0xffffffffu) excl += wave_sum[nw];
         if (tp != 0xffffffffu) break;
         base -= (long long)blockDim.x;
         __syncthreads();
@@ -776,7 +780,7 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
             u32 base = 0;
             if (listed) {
                 if (lane == 0) base = atomicAdd(&scratch[20], listed);
-                base = __shfl(base, 0);
+                base = (u32)__builtin_amdgcn_readfirstlane((int)base);
             }
 #pragma unroll
             for (int e = 0; e < E; ++e)
@@ -1218,14 +1222,12 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
             pre_sv = sets[lane];
         }
         u64 chain_in = (slot0 && have) ? bounds[lane * per + slot0] : 0ull;   // inputs in front of this chain
-        const u64 len = have ? pre_b1 - pre_b0 : 0ull;
-        u64 incl = len;
-#pragma unroll
-        for (int off = 1; off < KH_WAVE; off <<= 1) {
-            const u64 u = __shfl_up(incl, off);
-            if (lane >= (u32)off) incl += u;
-        }
-        const u64 n64 = __shfl(incl, KH_WAVE - 1);
+        // slice lengths are scanned as 32-bit values on the DPP path; a slice of 2^24 records or
+        // more is far beyond any slot capacity and only needs to be reported as "too full"
+        const u64 len64 = have ? pre_b1 - pre_b0 : 0ull;
+        const u32 len = len64 > 0xffffffull ? 0xffffffu : (u32)len64;
+        const u32 incl = wave_scan_add(len);
+        const u64 n64 = (u32)__builtin_amdgcn_readlane((int)incl, KH_WAVE - 1);
         if (slot0) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) chain_in += __shfl_xor(chain_in, off);
@@ -1241,7 +1243,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
             n = (u32)n64;
         }
         // operands that do not exist start "after everything"
-        const u32 soff = have ? (u32)(incl - len) : 0xffffffffu;
+        const u32 soff = have ? incl - len : 0xffffffffu;
         const u64 sbeg = pre_b0, skey = reinterpret_cast<u64>(pre_sv.keys), scnt = reinterpret_cast<u64>(pre_sv.counts);
         const u32 suni = pre_sv.uniform;
         auto lane64 = [](u64 v, u32 src) -> u64 {   // value of lane `src` (uniform), via scalar reads
