@@ -247,12 +247,19 @@ __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
 // sectors.  Needs 64 KiB of staging, so it is used while the genome's cursor table is small
 // enough for two workgroups per CU (host check); otherwise k_extract<1, true> runs.
 // ------------------------------------------------------------------------------------------
+// Staging geometry of pass B: one workgroup of 512 threads per CU stages 16384 keys (128 KiB), so
+// that a bucket's run in a flush is ~12 keys (96 bytes) instead of ~6.
+constexpr int KH_ST_SUB = 2 * KH_SUBTILE;                       // keys staged per round
+constexpr int KH_ST_ROUNDS = KH_TILE / KH_ST_SUB;               // rounds per tile
+constexpr u32 KH_ST_THREADS = 512;
+constexpr int KH_ST_PPT = KH_ST_SUB / KH_ST_THREADS;            // start positions per thread (32)
+constexpr int KH_ST_CODE_WORDS = (KH_ST_SUB + KH_HALO) / 16;
 size_t kh_extract_staged_lds_bytes(u32 nb_alloc) {
-    return (size_t)KH_SUBTILE * 8 + (size_t)nb_alloc * 4 + ((size_t)nb_alloc + 4) * 4 +
-           (size_t)KH_CODE_WORDS * 4 + (size_t)KH_CODE_WORDS * 2 + 8 + 64;
+    return (size_t)KH_ST_SUB * 8 + (size_t)nb_alloc * 4 + ((size_t)nb_alloc + 4) * 4 +
+           (size_t)KH_ST_CODE_WORDS * 4 + (size_t)KH_ST_CODE_WORDS * 2 + 8 + 64;
 }
 
-__global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict__ seq,
+__global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* __restrict__ seq,
                                                           const KhSeg* __restrict__ segs,
                                                           const KhTile* __restrict__ tiles,
                                                           u32 nb_alloc, int k,
@@ -260,30 +267,32 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
                                                           const u64* __restrict__ bstart,
                                                           KmerKey<1>* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
-    KmerKey<1>* stage = reinterpret_cast<KmerKey<1>*>(lds_raw);                 // [KH_SUBTILE]
-    u32* cur = reinterpret_cast<u32*>(lds_raw + (size_t)KH_SUBTILE * 8);         // [nb_alloc] global cursors
+    KmerKey<1>* stage = reinterpret_cast<KmerKey<1>*>(lds_raw);                 // [KH_ST_SUB]
+    u32* cur = reinterpret_cast<u32*>(lds_raw + (size_t)KH_ST_SUB * 8);         // [nb_alloc] global cursors
     u32* sub = cur + nb_alloc;                                                   // [nb_alloc + 4] sub-tile counts
     u32* code = sub + nb_alloc + 4;
-    u16* bad16 = reinterpret_cast<u16*>(code + KH_CODE_WORDS);
-    u32* wsum = reinterpret_cast<u32*>(bad16 + KH_CODE_WORDS + 4);               // [8] scan scratch
+    u16* bad16 = reinterpret_cast<u16*>(code + KH_ST_CODE_WORDS);
+    u32* wsum = reinterpret_cast<u32*>(bad16 + KH_ST_CODE_WORDS + 4);               // [8] scan scratch
 
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const KhTile t = tiles[blockIdx.x];
     const KhSeg sg = segs[t.seg];
     const u32 nb = sg.nbuckets;
     const u32* row = thist + sg.thist_base + (u64)t.tile_in_seg * nb;
-    for (u32 i = tid; i < nb; i += 256) cur[i] = row[i];
+    constexpr u32 NT = KH_ST_THREADS;
+    constexpr int PPT = KH_ST_PPT;
+    for (u32 i = tid; i < nb; i += NT) cur[i] = row[i];
     const u64 part_base = bstart[sg.bucket_base];
     const Roller<1> roller(k);
     const u8* sbase = sg.seq;
     const u64 tile_pos0 = (u64)t.tile_in_seg * KH_TILE;
-    const u32 per = (nb + 255) / 256;   // scan entries per thread (host guarantees <= 8)
+    const u32 per = (nb + NT - 1) / NT;   // scan entries per thread (host guarantees <= 4)
 
-    for (int sb = 0; sb < KH_SUBTILES_PER_TILE; ++sb) {
-        const u64 p0 = tile_pos0 + (u64)sb * KH_SUBTILE;
+    for (int sb = 0; sb < KH_ST_ROUNDS; ++sb) {
+        const u64 p0 = tile_pos0 + (u64)sb * KH_ST_SUB;
         if (p0 >= sg.npos) break;   // uniform over the block
         __syncthreads();            // previous sub-tile fully flushed, cursors advanced
-        for (u32 w = tid; w < (u32)KH_CODE_WORDS; w += 256) {
+        for (u32 w = tid; w < (u32)KH_ST_CODE_WORDS; w += NT) {
             const u64 b0 = p0 + 16ull * w;
             u32 codes = 0, bad = 0xffffu;
             if (b0 < sg.len) {
@@ -302,9 +311,9 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
             code[w] = codes;
             bad16[w] = (u16)bad;
         }
-        for (u32 i = tid; i <= nb; i += 256) sub[i] = 0;
+        for (u32 i = tid; i <= nb; i += NT) sub[i] = 0;
         __syncthreads();
-        // ---- A: extract; the key of this thread's start position st is staged at 256*st + tid
+        // ---- A: extract; the key of this thread's start position st is staged at NT*st + tid
         u32 vm = 0;   // which of the 32 start positions gave a key
         {
             KmerKey<1> f = key_zero<1>(), r = key_zero<1>();
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
                     if (st >= 0 && st < 32 && run >= k) {
                         KmerKey<1> can = key_lt(r, f) ? r : f;
                         can = kh_mix(can, k);
-                        stage[256 * st + tid] = can;   // position-major: conflict-free, and
+                        stage[NT * st + tid] = can;   // position-major: conflict-free, and
                         vm |= 1u << st;                // phase C reads back exactly these
                         atomicAdd(&sub[kh_slot<1>(can, k, nb)], 1u);
                     }
@@ -333,9 +342,9 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
         __syncthreads();
         // ---- B: exclusive scan of the bucket counts, in place (sub[b] = first staged index)
         {
-            u32 c[8], sum = 0;
+            u32 c[4], sum = 0;
 #pragma unroll
-            for (u32 j = 0; j < 8; ++j) {
+            for (u32 j = 0; j < 4; ++j) {
                 const u32 b = tid * per + j;
                 c[j] = (j < per && b < nb) ? sub[b] : 0u;
                 sum += c[j];
@@ -346,12 +355,12 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
             u32 run = incl - sum;
             for (u32 w = 0; w < wid; ++w) run += wsum[w];
 #pragma unroll
-            for (u32 j = 0; j < 8; ++j) {
+            for (u32 j = 0; j < 4; ++j) {
                 const u32 b = tid * per + j;
                 if (j < per && b < nb) sub[b] = run;
                 run += c[j];
             }
-            if (tid == 255) sub[nb] = run;   // total staged keys (threads past nb add nothing)
+            if (tid == NT - 1) sub[nb] = run;   // total staged keys (threads past nb add nothing)
         }
         __syncthreads();
         // ---- C/D: in-place counting sort by bucket through registers
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
                 key[j] = key_zero<1>();
                 u32 at = 0;
                 if (vm & (1u << j)) {
-                    key[j] = stage[256u * j + tid];
+                    key[j] = stage[NT * j + tid];
                     at = atomicAdd(&sub[kh_slot<1>(key[j], k, nb)], 1u);
                 }
                 if (j & 1) pos2[j >> 1] |= at << 16; else pos2[j >> 1] = at;
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
             const u32 nvalid = sub[nb];
 #pragma unroll 4
             for (int j = 0; j < 32; ++j) {
-                const u32 p = 256u * j + tid;
+                const u32 p = NT * j + tid;
                 if (p < nvalid) {
                     const KmerKey<1> key = stage[p];
                     const u32 b = kh_slot<1>(key, k, nb);
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void k_extract_staged(const u8* __restrict_
             }
         }
         __syncthreads();
-        for (u32 b = tid; b < nb; b += 256) cur[b] += sub[b] - (b ? sub[b - 1] : 0u);
+        for (u32 b = tid; b < nb; b += NT) cur[b] += sub[b] - (b ? sub[b - 1] : 0u);
     }
 }
 
@@ -1629,11 +1638,11 @@ void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, co
                        u32 ntiles, u32 nb_alloc, int k, u32* thist, const u64* bstart, void* part,
                        hipStream_t st) {
     if (!ntiles) return;
-    if (scatter && W == 1 && nb_alloc <= 2048 && kh_extract_staged_lds_bytes(nb_alloc) <= 80 * 1024 &&
+    if (scatter && W == 1 && nb_alloc <= 2048 && kh_extract_staged_lds_bytes(nb_alloc) <= 160 * 1024 &&
         !getenv("KHOICE_DIRECT_SCATTER")) {
         const size_t lds2 = kh_extract_staged_lds_bytes(nb_alloc);
         allow_lds(k_extract_staged, lds2);
-        hipLaunchKernelGGL(k_extract_staged, dim3(ntiles), dim3(256), lds2, st, seq, segs, tiles, nb_alloc, k,
+        hipLaunchKernelGGL(k_extract_staged, dim3(ntiles), dim3(KH_ST_THREADS), lds2, st, seq, segs, tiles, nb_alloc, k,
                            thist, bstart, reinterpret_cast<KmerKey<1>*>(part));
         return;
     }
