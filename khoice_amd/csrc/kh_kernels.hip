@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
 // that a bucket's run in a flush is ~12 keys (96 bytes) instead of ~6.
 constexpr int KH_ST_SUB = 2 * KH_SUBTILE;                       // keys staged per round
 constexpr int KH_ST_ROUNDS = KH_TILE / KH_ST_SUB;               // rounds per tile
-constexpr u32 KH_ST_THREADS = 512;
+constexpr u32 KH_ST_THREADS = 1024;
 constexpr int KH_ST_PPT = KH_ST_SUB / KH_ST_THREADS;            // start positions per thread (32)
 constexpr int KH_ST_CODE_WORDS = (KH_ST_SUB + KH_HALO) / 16;
 size_t kh_extract_staged_lds_bytes(u32 nb_alloc) {
@@ -314,14 +314,15 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
         for (u32 i = tid; i <= nb; i += NT) sub[i] = 0;
         __syncthreads();
         // ---- A: extract; the key of this thread's start position st is staged at NT*st + tid
-        u32 vm = 0;   // which of the 32 start positions gave a key
+        u32 vm = 0;   // which of the PPT start positions gave a key
         {
             KmerKey<1> f = key_zero<1>(), r = key_zero<1>();
             int run = 0;
-            const int last_base = 31 + k - 1;
+            const int last_base = PPT - 1 + k - 1;
+            constexpr u32 WPT = PPT / 16;   // code words of a thread's own positions
             for (int wi = 0; wi * 16 <= last_base; ++wi) {
-                const u32 cw = code[2 * tid + wi];
-                const u32 bw = bad16[2 * tid + wi];
+                const u32 cw = code[WPT * tid + wi];
+                const u32 bw = bad16[WPT * tid + wi];
 #pragma unroll 4
                 for (int j = 0; j < 16; ++j) {
                     const int u = wi * 16 + j;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
                     roller.push(f, r, c);
                     run = ((bw >> j) & 1u) ? 0 : run + 1;
                     const int st = u - (k - 1);
-                    if (st >= 0 && st < 32 && run >= k) {
+                    if (st >= 0 && st < PPT && run >= k) {
                         KmerKey<1> can = key_lt(r, f) ? r : f;
                         can = kh_mix(can, k);
                         stage[NT * st + tid] = can;   // position-major: conflict-free, and
@@ -365,10 +366,10 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
         __syncthreads();
         // ---- C/D: in-place counting sort by bucket through registers
         {
-            KmerKey<1> key[32];
-            u32 pos2[16];
+            KmerKey<1> key[PPT];
+            u32 pos2[PPT / 2];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
+            for (int j = 0; j < PPT; ++j) {
                 key[j] = key_zero<1>();
                 u32 at = 0;
                 if (vm & (1u << j)) {
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 32; ++j)
+            for (int j = 0; j < PPT; ++j)
                 if (vm & (1u << j)) stage[(pos2[j >> 1] >> (16 * (j & 1))) & 0xffffu] = key[j];
         }
         __syncthreads();
@@ -387,13 +388,17 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
         {
             const u32 nvalid = sub[nb];
 #pragma unroll 4
-            for (int j = 0; j < 32; ++j) {
+            for (int j = 0; j < PPT; ++j) {
                 const u32 p = NT * j + tid;
                 if (p < nvalid) {
                     const KmerKey<1> key = stage[p];
                     const u32 b = kh_slot<1>(key, k, nb);
                     const u32 first = b ? sub[b - 1] : 0u;
+#ifndef KH_DIAG_NO_SCATTER_STORE   // diagnostic builds only: how long pass B takes without its stores
                     part[part_base + cur[b] + (p - first)] = key;
+#else
+                    if (key.lo == 0x123456789abcdefull && b == 0xffffffffu) part[0] = key;
+#endif
                 }
             }
         }
