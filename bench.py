@@ -62,19 +62,50 @@ def kernel_algorithmic_bytes(name, st, k, nseq_bases):
         total = kmers * kb + distinct * kb           # plain sets: no counter array written
     elif name == "setop":
         total = st["setop_in"] * kb + st["setop_out"] * (kb + 4)
+    elif name == "union_tagged":
+        total = st["setop_in"] * kb                  # reads every genome set once; writes histograms only
     else:
         total = 0
     return total / launches
 
 
+def self_launch(ngpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU)
+    BEFORE this process has imported torch or touched HIP, relay rank 0's JSON line, and return
+    non-zero if any rank failed.  Children are plain subprocesses of this script with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, i.e. exactly what torch.distributed.run does."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(ngpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus),
+                   LOCAL_WORLD_SIZE=str(ngpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     import torch
     import torch.distributed as dist
 
@@ -175,6 +206,16 @@ def main():
     k1_ms = sum(kern[n]["ms"] for n in ("extract_hist", "bucket_plan", "extract_scatter", "bucket_sort_rle"))
     k1_bytes = st["bases"] + st["distinct"] * (8 * w + 4)
     kernel_ms = {n: round(v["ms"] / args.steps, 4) for n, v in kern.items()}
+    # whole path against SURVEY §8d's fused-path figure (read every base once, write every group
+    # union and the across-group union once, read the group sets once):
+    #   sum_g N_g + U (8W+4)  +  sum_g U_g 8W + V (8W+4)
+    # where U = sum of the group unions' sizes, V = size of the across-group union.  The fused
+    # engine path moves fewer bytes than that (no union is written when no set is requested), so
+    # this prices the step against the reference DAG's compulsory traffic, not against its own.
+    u_total = int(res["within_hist"][:, 1:].sum())
+    v_total = int(res["across_hist"][1:].sum()) if res.get("across_hist") is not None else 0
+    path_bytes = total_bases + u_total * (8 * w + 4) + u_total * 8 * w + v_total * (8 * w + 4)
+    path_gbs = path_bytes / (ms_per_step * 1e-3) / 1e9
 
     out = {
         "metric": "distinct k-mers/sec (k=31, canonical)" if args.k == 31 else f"distinct k-mers/sec (k={args.k}, canonical)",
@@ -193,6 +234,10 @@ def main():
                               "achieved": round(k1_bytes / (k1_ms * 1e-3) / 1e9, 1) if k1_ms else 0.0,
                               "frac": round(k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k1_ms else 0.0,
                               "unit": "GB/s"},
+        "path_roofline": {"bound": "hbm", "algorithmic_bytes_per_step": int(path_bytes),
+                          "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(path_gbs / HBM_PEAK_GBS, 4),
+                          "formula": "bases + U(8W+4) + U*8W + V(8W+4), SURVEY 8d"},
         "kernel_ms_per_step": kernel_ms,
         "replans": st["retries"], "order_fallbacks": st.get("order_fallbacks", 0),
         "setup_seconds": round(gen_s, 1),

@@ -70,7 +70,9 @@ int kh_cli_kmc(kh_ctx* ctx, const std::vector<std::string>& args, std::string& o
     if (pos.size() != 3) return kmc_usage(err, "expected <input> <output_prefix> <working_directory>");
     if (k < 1 || k > 64) return kmc_usage(err, "k must be in 1..64 for this build");
     if (ci < 1) ci = 1;
-    const uint32_t cx32 = cx >= 0xffffffffull ? KH_NO_MAX : (uint32_t)cx;
+    // KMC's own default (-cx1e9) means "no upper cut-off" for every counter this engine can hold;
+    // passing it through as a number made long inputs (chunked builds) refuse `-ci1` runs
+    const uint32_t cx32 = cx >= 1000000000ull ? KH_NO_MAX : (uint32_t)cx;
     const uint32_t cs32 = cs >= 0xffffffffull ? 0xfffffffeu : (uint32_t)cs;
     if (cs32 < 1) return kmc_usage(err, "-cs must be >= 1");
 

@@ -188,7 +188,7 @@ void kh_ctx::prof_collect() {
 }
 static const char* kClsNames[KC_COUNT] = {"extract_hist", "bucket_plan", "extract_scatter",
                                           "bucket_sort_rle", "range_bounds", "setop", "histogram",
-                                          "remix", "copy_in"};
+                                          "remix", "copy_in", "union_tagged"};
 
 // ------------------------------------------------------------------------------ ctx API
 extern "C" int kh_device_count(void) {
@@ -370,27 +370,49 @@ static void report_stamps(kh_ctx* c, const char* what, DevBuf* sb, u64 nparts) {
 #endif
 
 // ------------------------------------------------------------------------------ K1 build
+// What a grid-mode build (KhGrid, kh_launch.h) leaves behind: nothing has been synchronised when
+// build_once returns, the caller queues the tagged union behind it and waits once.
+struct GridBuild {
+    kh_ctx* c = nullptr;
+    u32 fan = 1;            // in: largest group (sets the slot fill of the tagged union)
+    u32 cap = 0;            // in: slot capacity of the tagged union
+    u32 nb = 0, S = 0, nb_total = 0;
+    u64 total_pos = 0, bases = 0;
+    DevBuf *okeys = nullptr, *bstart = nullptr, *off = nullptr, *distinct = nullptr, *lb = nullptr;
+    void* pin = nullptr;    // plan staging: must outlive the asynchronous upload
+    size_t pin_bytes = 0;
+    ~GridBuild() {
+        buf_unref(okeys); buf_unref(bstart); buf_unref(off); buf_unref(distinct); buf_unref(lb);
+        if (pin && c) c->pin_release(pin, pin_bytes);
+    }
+};
+
 static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
                       int on_device, int k, u32 ci, u32 cx, u32 cs, int with_counts, u32 mean,
-                      kh_set** out_sets, bool* capacity_hit) {
+                      kh_set** out_sets, bool* capacity_hit, bool* order_retry, GridBuild* grid = nullptr) {
     const int W = k <= 32 ? 1 : 2;
     const size_t kb = 8 * (size_t)W;
     hipStream_t st = c->st;
     *capacity_hit = false;
+    *order_retry = false;
 
     // ---- segment layout
     std::vector<KhSeg> segs(nseq);
     std::vector<u64> pack_off(nseq);
     std::vector<KhTile> tiles;
-    u64 seq_bytes = 0, total_pos = 0, thist_n = 0;
+    u64 seq_bytes = 0, total_pos = 0, thist_n = 0, bases = 0;
     u32 nb_total = 0, max_nb = 1;
+    u64 grid_nb = 1;   // grid mode: one bucket grid for every sequence, sized by the longest
+    if (grid)
+        for (int i = 0; i < nseq; ++i)
+            if (lens[i] >= (u64)k) grid_nb = std::max<u64>(grid_nb, (lens[i] - k + 1 + mean - 1) / mean);
     for (int i = 0; i < nseq; ++i) {
         KhSeg& s = segs[i];
         s.seq = nullptr;
         pack_off[i] = seq_bytes;
         s.len = lens[i];
         s.npos = lens[i] >= (u64)k ? lens[i] - k + 1 : 0;
-        const u64 want_b = std::max<u64>(1, (s.npos + mean - 1) / mean);
+        const u64 want_b = grid ? grid_nb : std::max<u64>(1, (s.npos + mean - 1) / mean);
         if (want_b > KH_MAX_BUCKETS_PER_SEG)
             return kh_fail(KH_E_ARG,
                            "sequence %d has %llu k-mer positions; at most %llu per sequence are "
@@ -408,7 +430,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         max_nb = std::max(max_nb, s.nbuckets);
         total_pos += s.npos;
         seq_bytes += (lens[i] + 15) & ~15ull;
-        c->stat.bases += lens[i];
+        bases += lens[i];
     }
     seq_bytes += 256;   // tail padding: 16-byte loads may run past the last base
     const u32 ntiles = (u32)tiles.size();
@@ -426,6 +448,30 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     TMP_ALLOC(d_scan, c, 8 * kh_exscan_tmp_words(nb_total));
     TMP_ALLOC(d_part, c, kb * std::max<u64>(1, total_pos));
     TMP_ALLOC(d_lb, c, 8 * (u64)nb_total + 64);
+    KhGrid kgrid{nullptr, nullptr, 0, 0};
+    if (grid) {
+        // sub-ranges per bucket: the tagged union's slot = one sub-range of one bucket in every
+        // genome; fill T with T + 5 sigma <= capacity, sigma <= sqrt(T * fan) (copies of one key
+        // inside a group arrive together; setop_prepare has the same rule)
+        const double zg = 5.0 * std::sqrt((double)std::max<u32>(1, grid->fan));
+        const double x = 0.5 * (-zg + std::sqrt(zg * zg + 4.0 * (double)grid->cap));
+        const u64 target = std::max<u64>(16, std::min<u64>((u64)grid->cap * 92 / 100, (u64)(x * x)));
+        const u64 per_bucket = (total_pos + grid_nb - 1) / grid_nb;       // keys of one bucket over all genomes
+        grid->S = (u32)std::max<u64>(1, (per_bucket + target - 1) / target);
+        if (grid->S > 4096 || grid_nb * grid->S > 0x7fffffffull)
+            return kh_fail(KH_E_ARG, "grid build: %llu sub-ranges per bucket", (unsigned long long)grid->S);
+        grid->c = c;
+        grid->nb = (u32)grid_nb;
+        grid->nb_total = nb_total;
+        grid->total_pos = total_pos;
+        grid->bases = bases;
+        grid->off = c->buf_alloc(2 * (size_t)nb_total * (grid->S + 1));
+        grid->distinct = c->buf_alloc(8 * (size_t)nseq);
+        if (!grid->off || !grid->distinct) return kh_fail(KH_E_NOMEM, "device allocation failed (bucket index)");
+        HIPCHK(hipMemsetAsync(grid->distinct->p, 0, 8 * (size_t)nseq, st));
+        kgrid = KhGrid{reinterpret_cast<u16*>(grid->off->p), reinterpret_cast<unsigned long long*>(grid->distinct->p),
+                       grid->S, grid->nb};
+    }
     DevBuf* okeys = c->buf_alloc(kb * std::max<u64>(1, total_pos));
     if (!okeys) return kh_fail(KH_E_NOMEM, "device allocation failed (output keys)");
     DevBuf* ocnt = nullptr;
@@ -514,13 +560,21 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
 #endif
     c->prof_begin(KC_BUCKET_SORT);
     kh_launch_bucket_sort(W, d_part.b->p, d_work.as<KhBucketWork>(), nb_total, k, okeys->p,
-                          ocnt ? reinterpret_cast<u32*>(ocnt->p) : nullptr, lb, ci, cx, cs, st);
+                          ocnt ? reinterpret_cast<u32*>(ocnt->p) : nullptr, lb, ci, cx, cs, kgrid, st);
     c->prof_end();
     HIPCHK(hipGetLastError());
 #ifdef KH_STAMPS
     report_stamps(c, "bucket_sort", d_stamps.b, nb_total);
     kh_debug_set_stamps(nullptr);
 #endif
+    if (grid) {   // hand the device state over; the caller synchronises
+        buf_ref(okeys); grid->okeys = okeys;
+        buf_ref(d_bstart.b); grid->bstart = d_bstart.b;
+        buf_ref(d_lb.b); grid->lb = d_lb.b;
+        grid->pin = plan_pin.p; grid->pin_bytes = plan_pin.bytes;
+        plan_pin.p = nullptr;
+        return KH_OK;
+    }
 
     // ---- read back set boundaries
     if (g_trace) g_t_build_submitted = now_ms();
@@ -538,11 +592,12 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         if (c->dynamic_order) return kh_fail(KH_E_INTERNAL, "look-back spin timed out in bucket sort");
         c->dynamic_order = true;          // index order did not hold: tickets from now on
         c->stat.order_fallbacks++;
-        *capacity_hit = true;             // same batch again (the caller's re-plan loop)
+        *order_retry = true;              // same batch again with the same plan
         return KH_OK;
     }
     if (err & KH_ERR_CAPACITY) { *capacity_hit = true; return KH_OK; }
     c->stat.kmers += nvalid;
+    c->stat.bases += bases;      // counted once per successful build, not per attempt
 
     for (int i = 0; i < nseq; ++i) {   // a segment's chain ends with its inclusive total
         const u64 n = desc[segs[i].bucket_base + segs[i].nbuckets - 1] & ((1ull << 62) - 1);
@@ -559,16 +614,24 @@ static int build_batch_plain(kh_ctx* c, int nseq, const uint8_t* const* seqs, co
                              int on_device, int k, u32 ci, u32 cx, u32 cs, int with_counts,
                              kh_set** out_sets) {
     u32 mean = k <= 32 ? KH_BUCKET_MEAN_W1 : KH_BUCKET_MEAN_W2;
-    for (int attempt = 0; attempt < 5; ++attempt) {
-        bool cap = false;
+    u64 max_pos = 0;
+    for (int i = 0; i < nseq; ++i)
+        if (lens[i] >= (u64)k) max_pos = std::max<u64>(max_pos, lens[i] - k + 1);
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        bool cap = false, again = false;
         for (int i = 0; i < nseq; ++i) out_sets[i] = nullptr;
-        int r = build_once(c, nseq, seqs, lens, on_device, k, ci, cx, cs, with_counts, mean, out_sets, &cap);
+        int r = build_once(c, nseq, seqs, lens, on_device, k, ci, cx, cs, with_counts, mean, out_sets, &cap, &again);
         if (r != KH_OK) return r;
+        if (again) continue;              // look-back order fallback: nothing overflowed, same plan
         if (!cap) return KH_OK;
         c->stat.retries++;
-        mean = std::max<u32>(64, mean / 4);
+        // more buckets, but never more than one segment's cursor table holds
+        const u32 floor_mean = (u32)std::max<u64>(64, (max_pos + KH_MAX_BUCKETS_PER_SEG - 1) / KH_MAX_BUCKETS_PER_SEG);
+        const u32 next = std::max<u32>(floor_mean, mean / 4);
+        if (next >= mean) break;
+        mean = next;
     }
-    return kh_fail(KH_E_CAPACITY, "a bucket still holds more distinct k-mers than fit in LDS after 5 re-plans");
+    return kh_fail(KH_E_CAPACITY, "a bucket still holds more distinct k-mers than fit in LDS after re-planning");
 }
 
 extern "C" int kh_build_batch(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
@@ -1368,6 +1431,167 @@ static int group_union_incremental(kh_ctx* c, const std::vector<int>& members, c
     return r;
 }
 
+// The fused form of steps 1-8 (no per-genome / per-group database is handed out): ONE batched build
+// in grid mode, ONE tagged union over all genomes, ONE host synchronisation.  *done == false on
+// return means "not applicable or a slot overflowed": the caller takes the general path.
+static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
+                      const int* group_of, int ngroups, int k, u32 cs, uint64_t* within_hist,
+                      uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, kh_set** across_set,
+                      bool* done) {
+    *done = false;
+    const int W = k <= 32 ? 1 : 2;
+    if (nseq > KH_TAG_MAX_OPS || ngroups > KH_TAG_MAX_OPS) return KH_OK;
+    // operands in group-major order: the genomes of a group are consecutive bits of the mask
+    std::vector<int> gsize(ngroups, 0), gstart(ngroups + 1, 0), perm(nseq);
+    for (int i = 0; i < nseq; ++i) gsize[group_of[i]]++;
+    u32 fan = 1, nbins = 0;
+    std::vector<u32> bin0(ngroups);
+    for (int g = 0; g < ngroups; ++g) {
+        if (!gsize[g]) return kh_fail(KH_E_ARG, "group %d has no sequences", g);
+        gstart[g + 1] = gstart[g] + gsize[g];
+        bin0[g] = nbins;
+        nbins += (u32)gsize[g] + 1;
+        fan = std::max<u32>(fan, (u32)gsize[g]);
+    }
+    const u32 abase = nbins;
+    nbins += (u32)ngroups + 1;
+    if (nbins > (u32)KH_TAG_MAX_BINS) return KH_OK;
+    {
+        std::vector<int> at(gstart.begin(), gstart.end() - 1);
+        for (int i = 0; i < nseq; ++i) perm[at[group_of[i]]++] = i;
+    }
+    const u32 mean = k <= 32 ? KH_BUCKET_MEAN_W1 : KH_BUCKET_MEAN_W2;
+    std::vector<const uint8_t*> pseq(nseq);
+    std::vector<uint64_t> plen(nseq);
+    for (int i = 0; i < nseq; ++i) {
+        pseq[i] = seqs[perm[i]];
+        plen[i] = lens[perm[i]];
+        // longer than one segment's bucket table: the general path cuts such sequences into chunks
+        if (lens[perm[i]] >= (u64)k && lens[perm[i]] - k + 1 > (u64)(KH_MAX_BUCKETS_PER_SEG / 4) * mean) return KH_OK;
+    }
+    HIPCHK(hipSetDevice(c->dev));
+    hipStream_t st = c->st;
+
+    GridBuild gb;
+    gb.fan = fan;
+    gb.cap = W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2;
+    bool cap_hit = false, again = false;
+    KHCHK(build_once(c, nseq, pseq.data(), plen.data(), on_device, k, 1, KH_NO_MAX, KH_KMC_DEFAULT_CS, 0, mean,
+                     nullptr, &cap_hit, &again, &gb));
+
+    // ---- tagged union queued behind the build
+    const u32 nslots = gb.nb * gb.S;
+    const bool emit = across_set != nullptr;
+    const u32 grid = nslots;
+    const u32 reps = std::min<u32>(256, std::max<u32>(1, grid));
+    // workspace: [hist: reps x nbins u64][ctl: 8 u32][out_n u64][ginfo: 64 u32][descriptors: nslots u64 when emitting]
+    const size_t hist_words = (size_t)reps * nbins;
+    const size_t ws_bytes = 8 * hist_words + 32 + 8 + 256 + (emit ? 8 * (size_t)nslots : 0);
+    Tmp d_ws;
+    TMP_ALLOC(d_ws, c, ws_bytes);
+    u8* wsp = d_ws.as<u8>();
+    struct PinG { kh_ctx* c; void* p = nullptr; size_t n = 0; ~PinG() { if (p) c->pin_release(p, n); } } pin{c};
+    // pinned staging: [ginfo upload: 64 u32][hist read-back][ctl + out_n: 40 B][distinct: nseq u64][pass C tail: 64 B][nvalid u64]
+    const size_t pin_need = 256 + 8 * hist_words + 40 + 8 * (size_t)nseq + 64 + 8;
+    pin.p = c->pin_alloc(pin_need, &pin.n);
+    if (!pin.p) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
+    u32* h_ginfo = static_cast<u32*>(pin.p);
+    u64* h_hist = reinterpret_cast<u64*>(h_ginfo + 64);
+    u32* h_ctl = reinterpret_cast<u32*>(h_hist + hist_words);
+    u64* h_distinct = reinterpret_cast<u64*>(h_ctl + 10);
+    u64* h_ctail = h_distinct + nseq;
+    u64* h_nvalid = h_ctail + 8;
+    memset(h_ginfo, 0, 256);
+    for (int g = 0; g < ngroups; ++g)
+        for (int j = 0; j < gsize[g]; ++j)
+            h_ginfo[gstart[g] + j] = (u32)gstart[g] | ((u32)gsize[g] << 8) | (bin0[g] << 16);
+    HIPCHK(hipMemsetAsync(wsp, 0, 8 * hist_words + 40, st));
+    HIPCHK(hipMemcpyAsync(wsp + 8 * hist_words + 40, h_ginfo, 256, hipMemcpyHostToDevice, st));
+    if (emit) HIPCHK(hipMemsetAsync(wsp + 8 * hist_words + 40 + 256, 0, 8 * (size_t)nslots, st));
+    DevBuf *okeys = nullptr, *ocnt = nullptr;
+    struct OutGuard { DevBuf*& a; DevBuf*& b; ~OutGuard() { buf_unref(a); buf_unref(b); } } og{okeys, ocnt};
+    if (emit) {
+        okeys = c->buf_alloc(8 * (size_t)W * std::max<u64>(1, gb.total_pos));
+        ocnt = c->buf_alloc(4 * std::max<u64>(1, gb.total_pos));
+        if (!okeys || !ocnt) return kh_fail(KH_E_NOMEM, "device allocation failed (across-group set)");
+    }
+    KhTagJob job;
+    job.keys = gb.okeys->p;
+    job.bstart = reinterpret_cast<const u64*>(gb.bstart->p);
+    job.off = reinterpret_cast<const u16*>(gb.off->p);
+    job.ginfo = reinterpret_cast<const u32*>(wsp + 8 * hist_words + 40);
+    job.hist = reinterpret_cast<unsigned long long*>(wsp);
+    job.ctl = reinterpret_cast<u32*>(wsp + 8 * hist_words);
+    job.nb = gb.nb; job.S = gb.S; job.nops = (u32)nseq; job.nbins = nbins; job.abase = abase;
+    job.ngroups = (u32)ngroups; job.reps = reps;
+    job.out_keys = emit ? okeys->p : nullptr;
+    job.out_counts = emit ? reinterpret_cast<u32*>(ocnt->p) : nullptr;
+    job.desc = emit ? reinterpret_cast<u64*>(wsp + 8 * hist_words + 40 + 256) : nullptr;
+    job.out_n = reinterpret_cast<unsigned long long*>(wsp + 8 * hist_words + 32);
+#ifdef KH_STAMPS
+    Tmp d_stamps;
+    TMP_ALLOC(d_stamps, c, 128 * (u64)grid);
+    HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * (u64)grid, st));
+    kh_debug_set_stamps(d_stamps.as<u64>());
+#endif
+    c->prof_begin(KC_UNION_TAGGED);
+    kh_launch_union_tagged(W, job, grid, k, cs, st);
+    c->prof_end();
+    HIPCHK(hipGetLastError());
+#ifdef KH_STAMPS
+    report_stamps(c, "union_tagged", d_stamps.b, grid);
+    kh_debug_set_stamps(nullptr);
+#endif
+    // ---- one read-back, one wait
+    HIPCHK(hipMemcpyAsync(h_hist, wsp, 8 * hist_words + 40, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_distinct, gb.distinct->p, 8 * (size_t)nseq, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_ctail, reinterpret_cast<u64*>(gb.lb->p) + gb.nb_total, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_nvalid, reinterpret_cast<u64*>(gb.bstart->p) + gb.nb_total, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const u32 cerr = reinterpret_cast<const u32*>(h_ctail)[1];   // pass C: [ticket, err]
+    const u32 uerr = h_ctl[0];
+    if ((cerr | uerr) & (KH_ERR_CAPACITY | KH_ERR_SPIN_TIMEOUT | KH_ERR_ORDER)) {
+        c->stat.retries++;
+        return KH_OK;   // a bucket or a slot did not fit: the general path re-plans
+    }
+    c->stat.bases += gb.bases;
+    c->stat.kmers += *h_nvalid;
+    c->stat.builds += nseq;
+    c->stat.setops++;
+    u64 dsum = 0;
+    for (int i = 0; i < nseq; ++i) {
+        if (distinct_per_seq) distinct_per_seq[perm[i]] = h_distinct[i];
+        dsum += h_distinct[i];
+    }
+    c->stat.distinct += dsum;
+    c->stat.setop_in += dsum;
+    std::vector<u64> bins(nbins, 0);
+    for (u32 r = 0; r < reps; ++r)
+        for (u32 b = 0; b < nbins; ++b) bins[b] += h_hist[(size_t)r * nbins + b];
+    if (within_hist) {
+        memset(within_hist, 0, 8 * (size_t)ngroups * hist_len);
+        for (int g = 0; g < ngroups; ++g)
+            for (int cnt = 1; cnt <= gsize[g]; ++cnt)
+                within_hist[(size_t)g * hist_len + std::min<u32>((u32)cnt, hist_len - 1)] += bins[bin0[g] + cnt];
+    }
+    u64 across_n = 0;
+    for (int cnt = 1; cnt <= ngroups; ++cnt) across_n += bins[abase + cnt];
+    c->stat.setop_out += across_n;
+    if (across_hist) {
+        memset(across_hist, 0, 8 * (size_t)hist_len);
+        for (int cnt = 1; cnt <= ngroups; ++cnt)
+            across_hist[std::min<u32>((u32)cnt, hist_len - 1)] += bins[abase + cnt];
+    }
+    if (emit) {
+        const u64 n = *reinterpret_cast<const u64*>(h_ctl + 8);
+        buf_ref(okeys);
+        buf_ref(ocnt);
+        *across_set = make_set(k, n, okeys, 0, ocnt, 0, 1, cs);
+    }
+    *done = true;
+    return KH_OK;
+}
+
 extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
                            int on_device, const int* group_of, int ngroups, int k, uint32_t cs,
                            uint64_t* within_hist, uint64_t* across_hist, uint32_t hist_len,
@@ -1378,6 +1602,26 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
     for (int i = 0; i < nseq; ++i)
         if (group_of[i] < 0 || group_of[i] >= ngroups)
             return kh_fail(KH_E_ARG, "group_of[%d]=%d outside [0,%d)", i, group_of[i], ngroups);
+    KHCHK(check_k(k));
+    if (cs < 1) return kh_fail(KH_E_ARG, "cs must be >= 1");
+    // No per-group database wanted and everything fits one wave: the fused form (one build in grid
+    // mode + one tagged union); anything it cannot take falls through to the general path below.
+    if (!group_sets && !getenv("KHOICE_NO_FUSED")) {
+        u64 all_bases = 0;
+        for (int i = 0; i < nseq; ++i) all_bases += lens[i];
+        u64 fbudget = 4ull << 30;
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipSetDevice(c->dev));
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            fbudget = std::max<u64>(1u << 20, (free_b + c->pool.cached_bytes) / (k <= 32 ? 64 : 96));
+        if (const char* e = getenv("KHOICE_WAVE_BASES")) fbudget = std::max<u64>(1, strtoull(e, nullptr, 10));
+        if (all_bases <= fbudget) {
+            bool done = false;
+            KHCHK(exp1_fused(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, within_hist, across_hist,
+                             hist_len, distinct_per_seq, across_set, &done));
+            if (done) return KH_OK;
+        }
+    }
     std::vector<kh_set*> gsets(nseq, nullptr), unions(ngroups, nullptr), usets(ngroups, nullptr);
     kh_set* across = nullptr;
     auto cleanup = [&]() {

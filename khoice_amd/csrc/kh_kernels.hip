@@ -977,6 +977,63 @@ __device__ u64 rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab,
 }
 
 // ------------------------------------------------------------------------------------------
+// Grid mode of pass C (fused experiment-type-1 path, KhGrid in kh_launch.h): the distinct keys
+// of the sorted bucket s[0..n) go to out[0..d) — the bucket's own place, known before the launch,
+// so nothing is waited for — together with the bucket's sub-range index off[0..S].
+// ------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ u32 kh_sub(const KmerKey<W>& key, int k, u32 nb, u32 S) {
+    const u32 frac = (u32)((u64)kh_top32(key, k) * (u64)nb);   // position inside the bucket
+    return (u32)(((u64)frac * (u64)S) >> 32);                  // == kh_slot(key, nb * S) - b * S
+}
+
+template <int W, int E>
+__device__ void grid_emit(const KmerKey<W>* s, const u32 n, u32* tab, KmerKey<W>* __restrict__ out,
+                          u16* __restrict__ off, const u32 S, int k, u32 nb,
+                          unsigned long long* __restrict__ distinct) {
+    constexpr u32 NT = KH_SORT_THREADS;
+    const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    KmerKey<W> cur[E], prv[E];
+    u32 lr[E], flags = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 i = (u32)e * NT + tid;
+        cur[e] = s[i < n ? i : 0];
+        prv[e] = s[(i < n && i) ? i - 1 : 0];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 i = (u32)e * NT + tid;
+        const bool head = (i < n) && (i == 0 || !key_eq(cur[e], prv[e]));
+        const u64 bal = __ballot(head);
+        if (lane == 0) tab[e * KH_SORT_NW + wid] = (u32)__popcll(bal);
+        lr[e] = (u32)__popcll(bal & lt_mask);
+        flags |= head ? (1u << e) : 0u;
+    }
+    table_scan<E>(tab);
+    KH_STAMP(0, 6);
+    KH_STAMP(0, 7);
+    const u32 d = tab[E * KH_SORT_NW];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (flags & (1u << e)) {
+            const u32 i = (u32)e * NT + tid;
+            const u32 rank = tab[e * KH_SORT_NW + wid] + lr[e];
+            out[rank] = cur[e];
+            // this key opens every sub-range after its predecessor's up to its own
+            const u32 sc = kh_sub<W>(cur[e], k, nb, S);
+            for (u32 f = i ? kh_sub<W>(prv[e], k, nb, S) + 1u : 0u; f <= sc; ++f) off[f] = (u16)rank;
+        }
+    }
+    // sub-ranges behind the last key (and the end marker off[S]) start at d
+    const u32 first_open = n ? kh_sub<W>(s[n - 1], k, nb, S) + 1u : 0u;
+    for (u32 t = first_open + tid; t <= S; t += NT) off[t] = (u16)d;
+    if (tid == 0 && d) atomicAdd(distinct, (unsigned long long)d);
+    KH_STAMP(0, 8);
+}
+
+// ------------------------------------------------------------------------------------------
 // pass C: per-bucket sort + run-length count + ordered output
 // ------------------------------------------------------------------------------------------
 // Normal buckets (n <= cap): keys-only distribution sort, counter = run length.
@@ -989,7 +1046,7 @@ template <int W>
 __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_bucket_sort_rle(
     const KmerKey<W>* __restrict__ part, const KhBucketWork* __restrict__ work, u32 cap, int k,
     KmerKey<W>* __restrict__ out_keys, u32* __restrict__ out_counts, KhLookback lb, u32 ci, u32 cx,
-    u32 cs) {
+    u32 cs, const KhGrid grid) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     const SortLds L{lds_raw, cap, W, false};
     KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
@@ -1047,6 +1104,11 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
         KH_STAMP(q, 1);
         distribute_sort<W, false, E>(kreg, preg, n, s, nullptr, reinterpret_cast<u32*>(hstart),
                                      tab + 128, tab + 128 + KH_FINE_BINS / 32, scratch, k, seg_nb, q);
+        if (grid.off) {
+            grid_emit<W, E>(s, n, tab, out_keys - wk.out_base + lo, grid.off + (u64)wk.gb * (grid.S + 1), grid.S,
+                            k, seg_nb, grid.distinct + wk.gb / grid.nb);
+            return;
+        }
         auto eval = [&](u32 h0, u32 h1) -> u32 {
             const u32 c = h1 - h0;
             return (c >= ci && c <= cx) ? c : 0u;
@@ -1095,6 +1157,11 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
         acc = 0;
     }
     // s[0..acc) now holds distinct keys with their counters in pay[] (acc <= capp < cap)
+    if (grid.off) {
+        grid_emit<W, E>(s, acc, tab, out_keys - wk.out_base + lo, grid.off + (u64)wk.gb * (grid.S + 1), grid.S, k,
+                        seg_nb, grid.distinct + wk.gb / grid.nb);
+        return;
+    }
     auto eval = [&](u32 h0, u32 h1) -> u32 {
         const u32 c = pay[h0];
         return (c >= ci && c <= cx) ? c : 0u;
@@ -1475,6 +1542,234 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
 }
 
 // ------------------------------------------------------------------------------------------
+// Tagged n-ary union over gridded genome sets (KhTagJob in kh_launch.h): steps 3+4 and 7+8 of
+// exp_type_1.smk in one pass, with no per-group database in between.  One workgroup per slot
+// r = b * S + f (looping over slots when nothing is emitted): lane g of every wave looks operand
+// g's slice up in the bucket index, the slices are gathered into registers with the operand
+// number as payload, sorted in LDS like any other set operation, and every run of equal keys is
+// turned into a genome mask by the thread that holds its first element.
+// ------------------------------------------------------------------------------------------
+template <int W, bool EMIT>
+__global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_union_tagged(
+    const KhTagJob jb, u32 cap, int k, u32 cs) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    const SortLds L{lds_raw, cap, W, true};
+    KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
+    u32* pay = reinterpret_cast<u32*>(lds_raw + L.pay_off());
+    u16* hstart = reinterpret_cast<u16*>(lds_raw + L.hstart_off());
+    u32* ginfo = reinterpret_cast<u32*>(lds_raw + L.lhist_off());              // [64], in the lhist region
+    u32* tab = reinterpret_cast<u32*>(lds_raw + L.tab_off());
+    u32* scratch = reinterpret_cast<u32*>(lds_raw + L.scratch_off());
+    // compact histogram, 8 copies per bin (copy = lane & 7).  It lives across the slots a
+    // workgroup walks, so it has a carve of its own behind the sort's (kh_tag_lds_bytes).
+    u32* hstripe = reinterpret_cast<u32*>(lds_raw + L.total());                // [nbins][8]
+    constexpr int CAPC = W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2;
+    constexpr int E = (CAPC + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
+    constexpr u32 NT = KH_SORT_THREADS;
+    const u32 tid = threadIdx.x, lane = lane_id();
+    const u32 nb = jb.nb, S = jb.S, nops = jb.nops, nbins = jb.nbins;
+    const u32 nslots = nb * S;
+    const KmerKey<W>* __restrict__ keys = reinterpret_cast<const KmerKey<W>*>(jb.keys);
+    constexpr bool emit = EMIT;
+    KmerKey<W>* __restrict__ out_keys = reinterpret_cast<KmerKey<W>*>(jb.out_keys);
+    u32* __restrict__ out_counts = jb.out_counts;
+    KhLookback lb;
+    lb.desc = jb.desc;
+    lb.ticket = jb.ctl + 2;
+    lb.err = jb.ctl;
+    lb.dynamic = 0;
+
+    for (u32 i = tid; i < (u32)KH_TAG_MAX_OPS; i += NT) ginfo[i] = jb.ginfo[i];
+    for (u32 i = tid; i < nbins * 8u; i += NT) hstripe[i] = 0;
+
+    // One slot per workgroup.  (A workgroup looping over slots kept the histogram in LDS longer, but
+    // the loop invariants hipcc hoisted out of it were spilled, and every scratch reload is an
+    // s_waitcnt vmcnt(0) in the middle of the gather: the eight key loads of a thread ran one
+    // after the other, 17 K cycles instead of 4 K.)
+    {
+        const u32 r = blockIdx.x;
+        const u32 b = r / S, f = r - b * S;
+        KH_STAMP(r, 0);
+        // ---- operand slices of this slot: lane g of every wave describes operand g
+        const bool have = lane < nops;
+        u64 sbeg = 0;
+        u32 len = 0;
+        if (have) {
+            const u32 gb = lane * nb + b;
+            const u16* __restrict__ o = jb.off + (u64)gb * (S + 1) + f;
+            const u32 o0 = o[0], o1 = o[1];
+            sbeg = jb.bstart[gb] + o0;
+            len = o1 >= o0 ? o1 - o0 : 0xffffffu;   // a corrupt index reads as "too full", never as a wrap
+        }
+        distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
+        const u32 incl = wave_scan_add(len);
+        const u32 n64 = (u32)__builtin_amdgcn_readlane((int)incl, KH_WAVE - 1);
+        u32 n = 0;
+        if (n64 > (u32)CAPC || n64 > cap) {
+            if (tid == 0) {
+                atomicOr(lb.err, KH_ERR_CAPACITY);
+                atomicMax(lb.err + 1, n64);
+            }
+        } else {
+            n = n64;
+        }
+        const u32 soff = have ? incl - len : 0xffffffffu;
+        auto lane64 = [](u64 v, u32 src) -> u64 {
+            const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, (int)src);
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), (int)src);
+            return ((u64)hi << 32) | lo;
+        };
+        KmerKey<W> kreg[E];
+        u32 preg[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            kreg[e] = key_zero<W>();
+            preg[e] = 0;
+            const u32 B = (u32)e * NT + (tid & ~(u32)(KH_WAVE - 1));
+            const u32 i = B + lane;
+            if (B >= n) continue;   // wave-uniform
+            const u32 g_lo = (u32)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(soff <= B))) - 1u;
+            const u32 g_hi = (u32)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(soff <= B + (KH_WAVE - 1)))) - 1u;
+            u32 ga = g_lo, my_soff;
+            u64 my_sbeg;
+            if (g_lo == g_hi) {
+                my_soff = (u32)__builtin_amdgcn_readlane((int)soff, (int)g_lo);
+                my_sbeg = lane64(sbeg, g_lo);
+            } else {   // operand boundaries inside the 64 elements: per-lane choice
+                for (u32 gg = g_lo + 1; gg <= g_hi; ++gg)
+                    ga += ((u32)__builtin_amdgcn_readlane((int)soff, (int)gg) <= i) ? 1u : 0u;
+                my_soff = __shfl(soff, ga);
+                my_sbeg = __shfl(sbeg, ga);
+            }
+            if (i < n) {
+                kreg[e] = keys[my_sbeg + (i - my_soff)];
+                preg[e] = ga;
+            }
+        }
+        __syncthreads();   // bins cleared; the previous slot's readers of s / pay are done
+#ifdef KH_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        KH_STAMP(r, 1);
+        distribute_sort<W, true, E>(kreg, preg, n, s, pay, reinterpret_cast<u32*>(hstart), tab + 128,
+                                    tab + 128 + KH_FINE_BINS / 32, scratch, k, nslots, r);
+        // ---- a run of equal keys -> genome mask -> per-group counts + number of groups
+        auto eval = [&](u32 h0, u32 h1) -> u32 {
+            u64 mask = 0;
+            for (u32 t = h0; t < h1; ++t) mask |= 1ull << (pay[t] & 63u);
+            u32 ng = 0;
+            while (mask) {
+                const u32 gi = ginfo[__ffsll((unsigned long long)mask) - 1];
+                const u32 g0 = gi & 0xffu, gn = (gi >> 8) & 0xffu, bin0 = gi >> 16;
+                const u64 gm = (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0;
+                u32 c = (u32)__popcll(mask & gm);
+                c = c < cs ? c : cs;
+                atomicAdd(&hstripe[(bin0 + c) * 8u + (lane & 7u)], 1u);
+                mask &= ~gm;
+                ++ng;
+            }
+            return ng < cs ? ng : cs;
+        };
+        if constexpr (!emit) {
+            // Nothing is written, so after the run heads are known the key array is free: it
+            // becomes one 64-bit genome mask per run, filled key-parallel with LDS atomics (no
+            // thread walks a run: a walk is a chain of dependent LDS reads).
+            const u64 le_mask = (2ull << lane) - 1ull;
+            const u32 wid = tid >> 6;
+            u32 rid[E], pv[E];
+            {
+                KmerKey<W> cur[E], prv[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u32 i = (u32)e * NT + tid;
+                    cur[e] = s[i < n ? i : 0];
+                    prv[e] = s[(i < n && i) ? i - 1 : 0];
+                    pv[e] = pay[i < n ? i : 0];
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u32 i = (u32)e * NT + tid;
+                    const bool head = (i < n) && (i == 0 || !key_eq(cur[e], prv[e]));
+                    const u64 bal = __ballot(head);
+                    if (lane == 0) tab[e * KH_SORT_NW + wid] = (u32)__popcll(bal);
+                    rid[e] = (u32)__popcll(bal & le_mask);   // heads of this wave's pass up to and including this lane
+                }
+            }
+            table_scan<E>(tab);   // its first barrier also ends every read of the keys
+            KH_STAMP(r, 6);
+            const u32 d = tab[E * KH_SORT_NW];
+            unsigned long long* rmask = reinterpret_cast<unsigned long long*>(s);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const u32 r0 = (u32)e * NT + tid;
+                if (r0 < d) rmask[r0] = 0ull;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const u32 i = (u32)e * NT + tid;
+                if (i < n) atomicOr(&rmask[tab[e * KH_SORT_NW + wid] + rid[e] - 1u], 1ull << (pv[e] & 63u));
+            }
+            __syncthreads();
+            KH_STAMP(r, 7);
+            u64 mk[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const u32 r0 = (u32)e * NT + tid;
+                mk[e] = r0 < d ? rmask[r0] : 0ull;
+            }
+            // first group of every run (nearly always the only one): table reads issued together
+            u32 gi[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) gi[e] = ginfo[mk[e] ? __ffsll((unsigned long long)mk[e]) - 1 : 0];
+            u32 ones = 0;   // runs that sit in exactly one group
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                u64 mask = mk[e];
+                if (!mask) continue;
+                u32 ng = 0, g = gi[e];
+                while (true) {
+                    const u32 g0 = g & 0xffu, gn = (g >> 8) & 0xffu, bin0 = g >> 16;
+                    const u64 gm = (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0;
+                    u32 c = (u32)__popcll(mask & gm);
+                    c = c < cs ? c : cs;
+                    atomicAdd(&hstripe[(bin0 + c) * 8u + (lane & 7u)], 1u);
+                    mask &= ~gm;
+                    ++ng;
+                    if (!mask) break;
+                    g = ginfo[__ffsll((unsigned long long)mask) - 1];
+                }
+                ng = ng < cs ? ng : cs;
+                if (ng == 1u) ++ones;
+                else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
+            }
+            // the across-group bin "1" would otherwise take one LDS atomic per key: per-wave sum
+            ones = wave_scan_add(ones);
+            if (lane == KH_WAVE - 1 && ones) atomicAdd(&hstripe[(jb.abase + 1u) * 8u], ones);
+            __syncthreads();
+            KH_STAMP(r, 8);
+        } else {
+            auto sink = [&](u64 o, const KmerKey<W>& key, u32 c) {
+                out_keys[o] = key;
+                out_counts[o] = c;
+                atomicAdd(&hstripe[(jb.abase + c) * 8u + (lane & 7u)], 1u);
+            };
+            const u64 chain_out = rle_emit<W, E>(s, n, hstart, tab, eval, sink, lb, r, scratch, true);
+            if (r == nslots - 1 && tid == 0) *jb.out_n = chain_out;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
+    for (u32 i = tid; i < nbins; i += NT) {
+        u32 v = 0;
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) v += hstripe[i * 8u + j];
+        if (v) atomicAdd(&rep[i], (unsigned long long)v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------
 // Block-private histogram whose low bins (where nearly all counters of a k-mer database fall)
@@ -1685,7 +1980,7 @@ void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st) 
 
 void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
                            u32 nbuckets, int k, void* out_keys, u32* out_counts, KhLookback lb,
-                           u32 ci, u32 cx, u32 cs, hipStream_t st) {
+                           u32 ci, u32 cx, u32 cs, const KhGrid& grid, hipStream_t st) {
     if (!nbuckets) return;
     const u32 cap = W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2;
     const size_t lds = kh_sort_lds_bytes(W, cap, false);
@@ -1693,13 +1988,29 @@ void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
         allow_lds(k_bucket_sort_rle<1>, lds);
         hipLaunchKernelGGL((k_bucket_sort_rle<1>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
                            reinterpret_cast<const KmerKey<1>*>(part), work, cap, k,
-                           reinterpret_cast<KmerKey<1>*>(out_keys), out_counts, lb, ci, cx, cs);
+                           reinterpret_cast<KmerKey<1>*>(out_keys), out_counts, lb, ci, cx, cs, grid);
     } else {
         allow_lds(k_bucket_sort_rle<2>, lds);
         hipLaunchKernelGGL((k_bucket_sort_rle<2>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
                            reinterpret_cast<const KmerKey<2>*>(part), work, cap, k,
-                           reinterpret_cast<KmerKey<2>*>(out_keys), out_counts, lb, ci, cx, cs);
+                           reinterpret_cast<KmerKey<2>*>(out_keys), out_counts, lb, ci, cx, cs, grid);
     }
+}
+
+size_t kh_tag_lds_bytes(int W, u32 cap, u32 nbins) { return kh_sort_lds_bytes(W, cap, true) + (size_t)nbins * 32; }
+void kh_launch_union_tagged(int W, const KhTagJob& job, u32 grid, int k, u32 cs, hipStream_t st) {
+    if (!grid) return;
+    const u32 cap = W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2;
+    const size_t lds = kh_tag_lds_bytes(W, cap, job.nbins);
+#define KH_UT(WW, EE)                                                                                   \
+    do {                                                                                                \
+        allow_lds(k_union_tagged<WW, EE>, lds);                                                         \
+        hipLaunchKernelGGL((k_union_tagged<WW, EE>), dim3(grid), dim3(KH_SORT_THREADS), lds, st, job, cap, k, cs); \
+    } while (0)
+    const bool emit = job.desc != nullptr;
+    if (W == 1) { if (emit) KH_UT(1, true); else KH_UT(1, false); }
+    else        { if (emit) KH_UT(2, true); else KH_UT(2, false); }
+#undef KH_UT
 }
 
 void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges, int k,

@@ -69,6 +69,46 @@ struct KhSetopJob {
 // wait for.  A chain adds its output count to ctl's u64 when its last slot finishes.
 struct KhSetopBatch { KhSetopJob job[KH_SETOP_BATCH]; };
 
+// ---- fused experiment-type-1 path (kh_exp1_run when no per-group set is wanted) ----
+// Pass C in GRID mode: every genome of the batch uses the SAME bucket grid (nb equal-width slots
+// of the mixed key space), a bucket's distinct keys are written where its input starts (index
+// `lo` of an output array laid out like the partition array: no compaction, hence no look-back
+// chain), and for every bucket an index of S + 1 u16 offsets is emitted: off[f] = number of the
+// bucket's keys in front of sub-range f (S equal-width sub-ranges of the bucket), off[S] = d.
+// Slot r = b * S + f of the key space then is, in EVERY genome g, the contiguous record range
+// [bstart[g*nb+b] + off[f], bstart[g*nb+b] + off[f+1]) — what a set operation otherwise finds by
+// binary search (k_range_bounds) is a table lookup.
+struct KhGrid {
+    u16* off;                       // [nseg * nb][S + 1]; nullptr: normal (compact, look-back) mode
+    unsigned long long* distinct;   // [nseg]: distinct keys per genome, added bucket by bucket
+    u32 S;
+    u32 nb;
+};
+// One tagged n-ary union over the gridded genome sets of up to 64 genomes: operand g carries tag
+// g, a run of equal keys becomes a 64-bit genome mask, and from the mask come, in ONE pass,
+//   * for every group holding the key, "in how many of its genomes" -> step_4 histograms,
+//   * "in how many groups"                                          -> step_8 histogram
+// (exp_type_1.smk:175-191, :243-259).  Histograms are compact: bin = first bin of the group +
+// count; across-group bins follow at `abase`.  A workgroup (one slot) keeps its histogram in LDS and
+// adds it to one of `reps` replicas in device memory (the host sums them): the replicas spread
+// what would otherwise be ~10^6 atomics per step on a handful of cache lines.
+constexpr int KH_TAG_MAX_OPS = 64;
+constexpr int KH_TAG_MAX_BINS = 255;
+struct KhTagJob {
+    const void* keys;           // gapped key arrays of all operands (one allocation)
+    const u64* bstart;          // [nops * nb + 1]
+    const u16* off;             // [nops * nb][S + 1]
+    const u32* ginfo;           // [64] per operand: first operand of its group | group size << 8 | first bin << 16
+    unsigned long long* hist;   // [reps][nbins]
+    u32* ctl;                   // [0] error bits, [1] fullest slot seen
+    u32 nb, S, nops, nbins, abase, ngroups, reps;
+    // optional ordered output (multi-GPU: the local across-group set, counter = groups holding the key)
+    void* out_keys;
+    u32* out_counts;
+    u64* desc;                  // look-back descriptors [nb * S], zeroed; nullptr: histograms only
+    unsigned long long* out_n;  // number of records written
+};
+
 struct KhLookback {      // workspace of one ordered single-pass launch
     u64* desc;           // [nparts] tile descriptors, zeroed before launch
     u32* ticket;         // zeroed before launch
@@ -80,7 +120,7 @@ struct KhLookback {      // workspace of one ordered single-pass launch
     // ever times out (KH_ERR_SPIN_TIMEOUT), re-running the launch.
     u32 dynamic;
 };
-enum : u32 { KH_ERR_SPIN_TIMEOUT = 1u, KH_ERR_CAPACITY = 2u };
+enum : u32 { KH_ERR_SPIN_TIMEOUT = 1u, KH_ERR_CAPACITY = 2u, KH_ERR_ORDER = 4u };
 
 size_t kh_extract_lds_bytes(u32 nb_alloc);
 size_t kh_sort_lds_bytes(int W, u32 cap, bool pay);
@@ -97,7 +137,9 @@ void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st);
 void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
                            u32 nbuckets, int k,
                            void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
-                           hipStream_t st);
+                           const KhGrid& grid, hipStream_t st);
+size_t kh_tag_lds_bytes(int W, u32 cap, u32 nbins);
+void kh_launch_union_tagged(int W, const KhTagJob& job, u32 grid, int k, u32 cs, hipStream_t st);
 void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges, int k,
                             u64* bounds, u64* zero, u64 zero_words, hipStream_t st);
 void kh_launch_range_bounds_batch(int W, const KhBoundsJob* jobs, u32 njobs, u64 max_threads, int k,

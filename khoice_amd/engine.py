@@ -425,10 +425,13 @@ class Engine:
 
     # -- fused experiment type 1
     def exp1_run(self, seqs: Sequence, group_of: Sequence[int], k: int, cs: int = 5000,
-                 hist_len: int = 5001, want_sets: bool = False, across: bool = True):
+                 hist_len: int = 5001, want_sets: bool = False, across: bool = True,
+                 want_across_set: bool = False):
         """Device side of exp_type_1.smk:156-259 for one k.  Returns a dict with
         within_hist[ngroups, hist_len], across_hist[hist_len], distinct_per_seq[nseq]
-        (and the group / across sets when want_sets)."""
+        (and the group / across sets when want_sets; only the across-group set, counter = groups
+        holding the k-mer, when want_across_set).  Without group sets the library takes its fused
+        form: one batched build + one tagged union, no per-group database in between."""
         ptrs, lens, on_dev, keep = self._seq_args(seqs)
         n = len(seqs)
         ng = max(group_of) + 1
@@ -442,13 +445,13 @@ class Engine:
         _check(self._lib.kh_exp1_run(self._ctx, n, ptrs, _u64p(lens), on_dev, gof, ng, k, cs,
                                      _u64p(within), _u64p(across) if do_across else None, hist_len,
                                      _u64p(distinct), gsets if want_sets else None,
-                                     C.byref(aset) if (want_sets and do_across) else None))
+                                     C.byref(aset) if ((want_sets and do_across) or want_across_set) else None))
         res = {"within_hist": within, "across_hist": across if do_across else None,
                "distinct_per_seq": distinct}
         if want_sets:
             res["group_sets"] = [KmerSet(self, gsets[i]) for i in range(ng)]
-            if do_across:
-                res["across_set"] = KmerSet(self, aset.value)
+        if (want_sets and do_across) or want_across_set:
+            res["across_set"] = KmerSet(self, aset.value)
         return res
 
 

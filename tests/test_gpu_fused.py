@@ -1,0 +1,120 @@
+"""The fused form of kh_exp1_run (one batched build in grid mode + one tagged union; taken when no
+per-group set is requested) against the C restatement and against the library's own general path
+(per-genome sets -> group unions -> across-group union) on the same inputs.  Bit-exact."""
+import random
+
+import numpy as np
+import pytest
+
+from khoice_amd import synth
+from oracle import c_oracle as CO
+from tests.util import random_dna
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from khoice_amd import build as kbuild
+    from khoice_amd import engine as E
+    kbuild.build_library()
+    e = E.Engine(0)
+    yield e
+    e.close()
+
+
+def check(eng, seqs, group_of, k, cs=5000, hist_len=5001, expect_fused=True):
+    want = CO.exp1(seqs, group_of, k, cs=cs, hist_len=hist_len)
+    before = eng.stats()["kernels"]["union_tagged"]["launches"]
+    eng.profile(True)
+    got = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len)
+    after = eng.stats()["kernels"]["union_tagged"]["launches"]
+    eng.profile(False)
+    if expect_fused:
+        assert after == before + 1, "the fused path did not run"
+    assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+    assert (got["within_hist"] == want["within_hist"]).all()
+    assert (got["across_hist"] == want["across_hist"]).all()
+    return got, want
+
+
+@pytest.mark.parametrize("k", [7, 15, 21, 31, 32, 33, 41, 63, 64])
+def test_fused_matches_oracle_over_k(eng, k):
+    items = synth.species_set(3, 3, 60_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    check(eng, seqs, group_of, k)
+
+
+def test_fused_edge_inputs(eng):
+    rng = random.Random(7)
+    anc = random_dna(rng, 30_000)
+    seqs = [
+        anc.encode(),
+        (anc[:15_000].lower() + "N" * 40 + anc[15_000:]).encode(),      # lower case, an N run
+        b"ACGT",                                                        # shorter than k
+        b"",                                                            # empty
+        ("A" * 20_000 + "\n" + anc[:5_000]).encode(),                   # low complexity: an oversize bucket
+        (">x\n" + anc[::-1]).encode(),                                  # header symbols break runs
+        random_dna(rng, 200).encode(),                                  # far shorter than the rest
+    ]
+    group_of = [0, 0, 0, 1, 1, 2, 2]
+    for k in (5, 21, 31, 47):
+        check(eng, seqs, group_of, k, cs=5000, hist_len=64)
+    check(eng, seqs, group_of, 31, cs=2, hist_len=64)                   # saturation of both counters
+    check(eng, seqs, group_of, 31, cs=5000, hist_len=3)                 # counters beyond the last bin
+    check(eng, [seqs[0]], [0], 31)                                      # one group of one genome
+    check(eng, [seqs[2], seqs[3]], [0, 1], 31)                          # nothing to count at all
+
+
+def test_fused_many_genomes_and_groups(eng):
+    """64 operands (the mask width), groups of very different sizes, shared blocks across groups."""
+    rng = random.Random(11)
+    shared = random_dna(rng, 3_000)
+    sizes = [1, 2, 30, 7, 24]
+    seqs, group_of = [], []
+    for g, sz in enumerate(sizes):
+        anc = random_dna(rng, 20_000)
+        for j in range(sz):
+            t = list(anc)
+            for _ in range(len(t) // 200):
+                t[rng.randrange(len(t))] = rng.choice("ACGT")
+            seqs.append(("".join(t) + ("N" + shared if j % 2 == 0 else "")).encode())
+            group_of.append(g)
+    assert len(seqs) == 64
+    order = list(range(64))
+    rng.shuffle(order)                                                  # callers need not pass groups in order
+    seqs = [seqs[i] for i in order]
+    group_of = [group_of[i] for i in order]
+    check(eng, seqs, group_of, 31)
+    check(eng, seqs, group_of, 41, cs=9, hist_len=40)
+    # one genome more: beyond the mask, the general path answers (same numbers)
+    check(eng, seqs + [seqs[0]], group_of + [group_of[0]], 31, expect_fused=False)
+
+
+def test_fused_equals_general_path_and_across_set(eng):
+    items = synth.species_set(4, 3, 150_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    for k in (31, 41):
+        fused = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64, want_across_set=True)
+        gen = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64, want_sets=True)
+        assert (fused["within_hist"] == gen["within_hist"]).all()
+        assert (fused["across_hist"] == gen["across_hist"]).all()
+        assert (fused["distinct_per_seq"] == gen["distinct_per_seq"]).all()
+        fk, fc = fused["across_set"].download_sorted()
+        gk, gc = gen["across_set"].download_sorted()
+        assert (fk == gk).all() and (fc == gc).all()
+        # the emitted set is a regular database: sorted by mixed key, usable by every operation
+        plain = [g.set_counts(1) for g in gen["group_sets"]]
+        x = eng.intersect(fused["across_set"], plain[0], "left", cs=5000)
+        assert len(x) == len(plain[0])
+
+
+def test_fused_full_size_genomes(eng):
+    """2 species x 3 genomes x 5 Mbp, k = 31: the bucket grid of real-size genomes (1351 buckets,
+    the staged scatter, sub-range index) against the C restatement."""
+    items = synth.species_set(2, 3, 5_000_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    check(eng, seqs, group_of, 31)
