@@ -107,8 +107,8 @@ __device__ __forceinline__ u64 lb_load(u64* p) {
 // ------------------------------------------------------------------------------------------
 // pass A / pass B: base decoding, rolling canonical k-mer, mixing, bucket histogram / scatter
 // ------------------------------------------------------------------------------------------
-constexpr int KH_HALO = 64;                                   // k-1 <= 63 extra bases
-constexpr int KH_CODE_WORDS = (KH_SUBTILE + KH_HALO) / 16;    // 516 words of 16 bases
+constexpr int KH_HALO = 96;                                   // k-1 <= 63 bases + two words of slack for the funnel shifts
+constexpr int KH_CODE_WORDS = (KH_SUBTILE + KH_HALO) / 16;    // words of 16 bases
 
 size_t kh_extract_lds_bytes(u32 nb_alloc) {
     return (size_t)nb_alloc * 4 + (size_t)KH_CODE_WORDS * 4 + (size_t)KH_CODE_WORDS * 2 + 16;
@@ -127,6 +127,32 @@ __device__ __forceinline__ void decode16(const uint4 v, u32& codes, u32& bad) {
         const bool ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
         codes |= code << (2 * i);
         bad |= (ok ? 0u : 1u) << i;
+    }
+}
+
+// Bases [p0, p0 + 16 * nwords) of a sequence -> LDS: code[w] = 16 two-bit codes (base j of the
+// word at bits 2j), bad16[w] = 16 "breaks a k-mer" flags (not ACGTacgt, or past the end).
+template <u32 NT>
+__device__ __forceinline__ void load_codes(const u8* __restrict__ sbase, const u64 len, const u64 p0,
+                                           u32* code, u16* bad16, const u32 nwords) {
+    for (u32 w = threadIdx.x; w < nwords; w += NT) {
+        const u64 b0 = p0 + 16ull * w;
+        u32 codes = 0, bad = 0xffffu;
+        if (b0 < len) {
+            const u64 left = len - b0;
+            uint4 v;
+            if (left >= 16) {
+                v = *reinterpret_cast<const uint4*>(sbase + b0);
+            } else {   // last, partial word of the sequence: never touch bytes past its end
+                u32 w4[4] = {0, 0, 0, 0};
+                for (u32 i = 0; i < (u32)left; ++i) w4[i >> 2] |= (u32)sbase[b0 + i] << (8 * (i & 3));
+                v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+            decode16(v, codes, bad);
+            if (left < 16) bad |= (0xffffu << (u32)left) & 0xffffu;
+        }
+        code[w] = codes;
+        bad16[w] = (u16)bad;
     }
 }
 
@@ -153,6 +179,79 @@ template <int W> __device__ __forceinline__ KmerKey<W> key_zero();
 template <> __device__ __forceinline__ KmerKey<1> key_zero<1>() { return KmerKey<1>{0}; }
 template <> __device__ __forceinline__ KmerKey<2> key_zero<2>() { return KmerKey<2>{0, 0}; }
 
+// reverse the order of the 32 two-bit groups of x
+__device__ __forceinline__ u64 kh_revpairs64(u64 x) {
+    x = ((u64)__builtin_bitreverse32((u32)x) << 32) | (u64)__builtin_bitreverse32((u32)(x >> 32));
+    return ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+}
+
+// Roller state after the m = k-1 bases in front of a thread's first k-mer end, straight from the
+// packed window X (base i of the window at bits 2i) instead of m pushes:
+//   forward word  = the window with the order of its bases reversed (first base most significant),
+//   reverse word  = the complemented window, two bits up (every later push shifts it down by one base).
+__device__ __forceinline__ void window_state(const u32 (&xw)[2], int m, KmerKey<1>& f, KmerKey<1>& r) {
+    const u64 x = (((u64)xw[1] << 32) | xw[0]) & kh_mask(2 * m);
+    f.lo = m ? kh_revpairs64(x) >> (64 - 2 * m) : 0ull;
+    r.lo = ((~x) & kh_mask(2 * m)) << 2;
+}
+__device__ __forceinline__ void window_state(const u32 (&xw)[4], int m, KmerKey<2>& f, KmerKey<2>& r) {
+    // 32 <= m <= 63 bases: 2m bits in (xhi, xlo)
+    const u64 xlo = ((u64)xw[1] << 32) | xw[0];
+    const u64 xhi = (((u64)xw[3] << 32) | xw[2]) & kh_mask(2 * m - 64);
+    const u64 revhi = kh_revpairs64(xlo), revlo = kh_revpairs64(xhi);   // 128-bit group reversal
+    const int s = 128 - 2 * m;                                           // 2 .. 64
+    if (s >= 64) { f.lo = revhi; f.hi = 0; }
+    else { f.lo = (revlo >> s) | (revhi << (64 - s)); f.hi = revhi >> s; }
+    r.lo = (~xlo) << 2;
+    r.hi = (((~xhi) & kh_mask(2 * m - 64)) << 2) | ((~xlo) >> 62);
+}
+
+// Canonical mixed keys of the PPT k-mers that start at bases p .. p + PPT - 1 of the sub-tile held
+// in code / bad16 (p = PPT * thread): emit(j, key) is called for every start p + j whose k bases are
+// all valid.  One window lookup, then exactly PPT pushes with compile-time bit positions.
+template <int W, int PPT, class Emit>
+__device__ __forceinline__ void extract_positions(const u32* code, const u16* bad16, const u32 p, const int k,
+                                                  const Roller<W>& roller, Emit emit) {
+    constexpr int NPRE = W == 1 ? 2 : 4;            // code words that hold the k-1 leading bases
+    constexpr int NNEW = (PPT + 15) / 16;           // code words of the PPT bases that end the k-mers
+    const int m = k - 1;
+    const u32 w0 = p >> 4, o = p & 15u;
+    const u32 q = p + (u32)m, wq = q >> 4, oq = q & 15u;
+    // all LDS reads of the thread are issued before the first is used
+    u32 cw[NPRE + 1], nw[NNEW + 1], bw[5], bn[3];
+#pragma unroll
+    for (int i = 0; i <= NPRE; ++i) cw[i] = code[w0 + i];
+#pragma unroll
+    for (int i = 0; i <= NNEW; ++i) nw[i] = code[wq + i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) bw[i] = bad16[w0 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bn[i] = bad16[wq + i];
+    u32 xw[NPRE], newc[NNEW];
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) xw[i] = __builtin_amdgcn_alignbit(cw[i + 1], cw[i], 2 * o);
+#pragma unroll
+    for (int i = 0; i < NNEW; ++i) newc[i] = __builtin_amdgcn_alignbit(nw[i + 1], nw[i], 2 * oq);
+    const u64 bpre = ((((u64)bw[4] << 48) | ((u64)bw[3] << 32) | ((u64)bw[2] << 16) | (u64)bw[1]) << (16 - o)) |
+                     ((u64)bw[0] >> o);             // flags of bases p .. p+63
+    const u64 newbad = (((u64)bn[2] << 32) | ((u64)bn[1] << 16) | (u64)bn[0]) >> oq;   // flags of bases q .. q+PPT-1
+    KmerKey<W> f, r;
+    window_state(xw, m, f, r);
+    // valid bases since the last break inside the window (the window itself when it has none)
+    const u64 bm = bpre & kh_mask(m);
+    int run = bm ? m - 64 + (int)__builtin_clzll(bm) : m;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const u32 c = (newc[j >> 4] >> (2 * (j & 15))) & 3u;
+        roller.push(f, r, c);
+        run = ((newbad >> j) & 1ull) ? 0 : run + 1;
+        if (run >= k) {
+            KmerKey<W> can = key_lt(r, f) ? r : f;
+            emit(j, kh_mix(can, k));
+        }
+    }
+}
+
 template <int W, bool SCATTER>
 __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
                                                 const KhSeg* __restrict__ segs,
@@ -176,61 +275,24 @@ __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
     if (SCATTER) part_base = bstart[sg.bucket_base];
 
     const Roller<W> roller(k);
-    const u8* sbase = sg.seq;
     const u64 tile_pos0 = (u64)t.tile_in_seg * KH_TILE;
+    constexpr int PPT = KH_SUBTILE / 256;   // 32 start positions per thread
 
     for (int sub = 0; sub < KH_SUBTILES_PER_TILE; ++sub) {
         const u64 p0 = tile_pos0 + (u64)sub * KH_SUBTILE;
         if (p0 >= sg.npos) break;   // uniform over the block
         __syncthreads();            // cursor init done / previous sub-tile fully consumed
-        for (u32 w = tid; w < (u32)KH_CODE_WORDS; w += 256) {
-            const u64 b0 = p0 + 16ull * w;
-            u32 codes = 0, bad = 0xffffu;
-            if (b0 < sg.len) {
-                const u64 left = sg.len - b0;
-                uint4 v;
-                if (left >= 16) {
-                    v = *reinterpret_cast<const uint4*>(sbase + b0);
-                } else {   // last, partial word of the sequence: never touch bytes past its end
-                    u32 w4[4] = {0, 0, 0, 0};
-                    for (u32 i = 0; i < (u32)left; ++i) w4[i >> 2] |= (u32)sbase[b0 + i] << (8 * (i & 3));
-                    v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                }
-                decode16(v, codes, bad);
-                if (left < 16) bad |= (0xffffu << (u32)left) & 0xffffu;
-            }
-            code[w] = codes;
-            bad16[w] = (u16)bad;
-        }
+        load_codes<256>(sg.seq, sg.len, p0, code, bad16, (u32)KH_CODE_WORDS);
         __syncthreads();
-        // thread handles start positions 32*tid .. 32*tid+31 of this sub-tile; it needs
-        // bases 32*tid .. 32*tid + 30 + k, i.e. at most 6 code words.
-        KmerKey<W> f = key_zero<W>(), r = key_zero<W>();
-        int run = 0;
-        const int last_base = 31 + k - 1;   // index (relative to 32*tid) of the last base needed
-        for (int wi = 0; wi * 16 <= last_base; ++wi) {
-            const u32 cw = code[2 * tid + wi];
-            const u32 bw = bad16[2 * tid + wi];
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
-                const int u = wi * 16 + j;
-                const u32 c = (cw >> (2 * j)) & 3u;
-                roller.push(f, r, c);
-                run = ((bw >> j) & 1u) ? 0 : run + 1;
-                const int st = u - (k - 1);
-                if (st >= 0 && st < 32 && run >= k) {
-                    KmerKey<W> can = key_lt(r, f) ? r : f;
-                    can = kh_mix(can, k);
-                    const u32 slot = kh_slot<W>(can, k, nb);
-                    if (SCATTER) {
-                        const u32 pos = atomicAdd(&cur[slot], 1u);
-                        part[part_base + pos] = can;
-                    } else {
-                        atomicAdd(&cur[slot], 1u);
-                    }
-                }
+        extract_positions<W, PPT>(code, bad16, (u32)PPT * tid, k, roller, [&](int, const KmerKey<W>& can) {
+            const u32 slot = kh_slot<W>(can, k, nb);
+            if (SCATTER) {
+                const u32 pos = atomicAdd(&cur[slot], 1u);
+                part[part_base + pos] = can;
+            } else {
+                atomicAdd(&cur[slot], 1u);
             }
-        }
+        });
     }
     if (!SCATTER) {
         __syncthreads();
@@ -239,40 +301,43 @@ __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
 }
 
 // ------------------------------------------------------------------------------------------
-// pass B with write combining (W = 1).  The direct form above stores every key as a lone 8-byte
+// pass B with write combining.  The direct form above stores every key as a lone 8W-byte
 // write; the lines are evicted from L2 before their neighbours arrive and HBM sees 3.3x the
-// bytes (measured: WRITE_SIZE 6.6 GB for 2.0 GB of keys).  Here a sub-tile's keys are first
+// bytes (measured: WRITE_SIZE 6.6 GB for 2.0 GB of keys).  Here a round's keys are first
 // counting-sorted by bucket inside LDS (through registers, in place), so that consecutive lanes
 // then store consecutive keys of one bucket run: the same bytes reach HBM in far fewer, fuller
-// sectors.  Needs 64 KiB of staging, so it is used while the genome's cursor table is small
-// enough for two workgroups per CU (host check); otherwise k_extract<1, true> runs.
+// sectors.  One workgroup of 1024 threads per CU stages 128 KiB of keys per round: 16384
+// one-word keys (a bucket's run in a flush is ~12 keys), 8192 two-word keys.
 // ------------------------------------------------------------------------------------------
-// Staging geometry of pass B: one workgroup of 512 threads per CU stages 16384 keys (128 KiB), so
-// that a bucket's run in a flush is ~12 keys (96 bytes) instead of ~6.
-constexpr int KH_ST_SUB = 2 * KH_SUBTILE;                       // keys staged per round
-constexpr int KH_ST_ROUNDS = KH_TILE / KH_ST_SUB;               // rounds per tile
 constexpr u32 KH_ST_THREADS = 1024;
-constexpr int KH_ST_PPT = KH_ST_SUB / KH_ST_THREADS;            // start positions per thread (32)
-constexpr int KH_ST_CODE_WORDS = (KH_ST_SUB + KH_HALO) / 16;
-size_t kh_extract_staged_lds_bytes(u32 nb_alloc) {
-    return (size_t)KH_ST_SUB * 8 + (size_t)nb_alloc * 4 + ((size_t)nb_alloc + 4) * 4 +
-           (size_t)KH_ST_CODE_WORDS * 4 + (size_t)KH_ST_CODE_WORDS * 2 + 8 + 64;
+template <int W> struct StageGeo {
+    static constexpr int SUB = W == 1 ? 2 * KH_SUBTILE : KH_SUBTILE;     // keys staged per round
+    static constexpr int ROUNDS = KH_TILE / SUB;                          // rounds per tile
+    static constexpr int PPT = SUB / (int)KH_ST_THREADS;                  // start positions per thread (16 / 8)
+    static constexpr int CODE_WORDS = (SUB + KH_HALO) / 16;
+};
+size_t kh_extract_staged_lds_bytes(int W, u32 nb_alloc) {
+    const size_t sub = W == 1 ? StageGeo<1>::SUB : StageGeo<2>::SUB;
+    const size_t cw = W == 1 ? StageGeo<1>::CODE_WORDS : StageGeo<2>::CODE_WORDS;
+    return sub * 8 * W + (size_t)nb_alloc * 4 + ((size_t)nb_alloc + 4) * 4 + cw * 4 + cw * 2 + 8 + 64;
 }
 
+template <int W>
 __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* __restrict__ seq,
                                                           const KhSeg* __restrict__ segs,
                                                           const KhTile* __restrict__ tiles,
                                                           u32 nb_alloc, int k,
                                                           const u32* __restrict__ thist,
                                                           const u64* __restrict__ bstart,
-                                                          KmerKey<1>* __restrict__ part) {
+                                                          KmerKey<W>* __restrict__ part) {
+    using G = StageGeo<W>;
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
-    KmerKey<1>* stage = reinterpret_cast<KmerKey<1>*>(lds_raw);                 // [KH_ST_SUB]
-    u32* cur = reinterpret_cast<u32*>(lds_raw + (size_t)KH_ST_SUB * 8);         // [nb_alloc] global cursors
-    u32* sub = cur + nb_alloc;                                                   // [nb_alloc + 4] sub-tile counts
+    KmerKey<W>* stage = reinterpret_cast<KmerKey<W>*>(lds_raw);                      // [SUB]
+    u32* cur = reinterpret_cast<u32*>(lds_raw + (size_t)G::SUB * 8 * W);             // [nb_alloc] global cursors
+    u32* sub = cur + nb_alloc;                                                       // [nb_alloc + 4] round counts
     u32* code = sub + nb_alloc + 4;
-    u16* bad16 = reinterpret_cast<u16*>(code + KH_ST_CODE_WORDS);
-    u32* wsum = reinterpret_cast<u32*>(bad16 + KH_ST_CODE_WORDS + 4);               // [8] scan scratch
+    u16* bad16 = reinterpret_cast<u16*>(code + G::CODE_WORDS);
+    u32* wsum = reinterpret_cast<u32*>(bad16 + G::CODE_WORDS + 4);                   // [16] scan scratch
 
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const KhTile t = tiles[blockIdx.x];
@@ -280,66 +345,27 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
     const u32 nb = sg.nbuckets;
     const u32* row = thist + sg.thist_base + (u64)t.tile_in_seg * nb;
     constexpr u32 NT = KH_ST_THREADS;
-    constexpr int PPT = KH_ST_PPT;
+    constexpr int PPT = G::PPT;
     for (u32 i = tid; i < nb; i += NT) cur[i] = row[i];
     const u64 part_base = bstart[sg.bucket_base];
-    const Roller<1> roller(k);
-    const u8* sbase = sg.seq;
+    const Roller<W> roller(k);
     const u64 tile_pos0 = (u64)t.tile_in_seg * KH_TILE;
     const u32 per = (nb + NT - 1) / NT;   // scan entries per thread (host guarantees <= 4)
 
-    for (int sb = 0; sb < KH_ST_ROUNDS; ++sb) {
-        const u64 p0 = tile_pos0 + (u64)sb * KH_ST_SUB;
+    for (int sb = 0; sb < G::ROUNDS; ++sb) {
+        const u64 p0 = tile_pos0 + (u64)sb * G::SUB;
         if (p0 >= sg.npos) break;   // uniform over the block
-        __syncthreads();            // previous sub-tile fully flushed, cursors advanced
-        for (u32 w = tid; w < (u32)KH_ST_CODE_WORDS; w += NT) {
-            const u64 b0 = p0 + 16ull * w;
-            u32 codes = 0, bad = 0xffffu;
-            if (b0 < sg.len) {
-                const u64 left = sg.len - b0;
-                uint4 v;
-                if (left >= 16) {
-                    v = *reinterpret_cast<const uint4*>(sbase + b0);
-                } else {   // last, partial word of the sequence: never touch bytes past its end
-                    u32 w4[4] = {0, 0, 0, 0};
-                    for (u32 i = 0; i < (u32)left; ++i) w4[i >> 2] |= (u32)sbase[b0 + i] << (8 * (i & 3));
-                    v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                }
-                decode16(v, codes, bad);
-                if (left < 16) bad |= (0xffffu << (u32)left) & 0xffffu;
-            }
-            code[w] = codes;
-            bad16[w] = (u16)bad;
-        }
+        __syncthreads();            // previous round fully flushed, cursors advanced
+        load_codes<NT>(sg.seq, sg.len, p0, code, bad16, (u32)G::CODE_WORDS);
         for (u32 i = tid; i <= nb; i += NT) sub[i] = 0;
         __syncthreads();
-        // ---- A: extract; the key of this thread's start position st is staged at NT*st + tid
+        // ---- A: extract; the key of this thread's start position j is staged at NT*j + tid
         u32 vm = 0;   // which of the PPT start positions gave a key
-        {
-            KmerKey<1> f = key_zero<1>(), r = key_zero<1>();
-            int run = 0;
-            const int last_base = PPT - 1 + k - 1;
-            constexpr u32 WPT = PPT / 16;   // code words of a thread's own positions
-            for (int wi = 0; wi * 16 <= last_base; ++wi) {
-                const u32 cw = code[WPT * tid + wi];
-                const u32 bw = bad16[WPT * tid + wi];
-#pragma unroll 4
-                for (int j = 0; j < 16; ++j) {
-                    const int u = wi * 16 + j;
-                    const u32 c = (cw >> (2 * j)) & 3u;
-                    roller.push(f, r, c);
-                    run = ((bw >> j) & 1u) ? 0 : run + 1;
-                    const int st = u - (k - 1);
-                    if (st >= 0 && st < PPT && run >= k) {
-                        KmerKey<1> can = key_lt(r, f) ? r : f;
-                        can = kh_mix(can, k);
-                        stage[NT * st + tid] = can;   // position-major: conflict-free, and
-                        vm |= 1u << st;                // phase C reads back exactly these
-                        atomicAdd(&sub[kh_slot<1>(can, k, nb)], 1u);
-                    }
-                }
-            }
-        }
+        extract_positions<W, PPT>(code, bad16, (u32)PPT * tid, k, roller, [&](int j, const KmerKey<W>& can) {
+            stage[NT * (u32)j + tid] = can;   // position-major: conflict-free, and
+            vm |= 1u << j;                     // phase C reads back exactly these
+            atomicAdd(&sub[kh_slot<W>(can, k, nb)], 1u);
+        });
         __syncthreads();
         // ---- B: exclusive scan of the bucket counts, in place (sub[b] = first staged index)
         {
@@ -366,15 +392,15 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
         __syncthreads();
         // ---- C/D: in-place counting sort by bucket through registers
         {
-            KmerKey<1> key[PPT];
+            KmerKey<W> key[PPT];
             u32 pos2[PPT / 2];
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
-                key[j] = key_zero<1>();
+                key[j] = key_zero<W>();
                 u32 at = 0;
                 if (vm & (1u << j)) {
                     key[j] = stage[NT * j + tid];
-                    at = atomicAdd(&sub[kh_slot<1>(key[j], k, nb)], 1u);
+                    at = atomicAdd(&sub[kh_slot<W>(key[j], k, nb)], 1u);
                 }
                 if (j & 1) pos2[j >> 1] |= at << 16; else pos2[j >> 1] = at;
             }
@@ -391,8 +417,8 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
             for (int j = 0; j < PPT; ++j) {
                 const u32 p = NT * j + tid;
                 if (p < nvalid) {
-                    const KmerKey<1> key = stage[p];
-                    const u32 b = kh_slot<1>(key, k, nb);
+                    const KmerKey<W> key = stage[p];
+                    const u32 b = kh_slot<W>(key, k, nb);
                     const u32 first = b ? sub[b - 1] : 0u;
 #ifndef KH_DIAG_NO_SCATTER_STORE   // diagnostic builds only: how long pass B takes without its stores
                     part[part_base + cur[b] + (p - first)] = key;
@@ -1938,12 +1964,18 @@ void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, co
                        u32 ntiles, u32 nb_alloc, int k, u32* thist, const u64* bstart, void* part,
                        hipStream_t st) {
     if (!ntiles) return;
-    if (scatter && W == 1 && nb_alloc <= 2048 && kh_extract_staged_lds_bytes(nb_alloc) <= 160 * 1024 &&
+    if (scatter && nb_alloc <= 4 * KH_ST_THREADS && kh_extract_staged_lds_bytes(W, nb_alloc) <= 160 * 1024 &&
         !getenv("KHOICE_DIRECT_SCATTER")) {
-        const size_t lds2 = kh_extract_staged_lds_bytes(nb_alloc);
-        allow_lds(k_extract_staged, lds2);
-        hipLaunchKernelGGL(k_extract_staged, dim3(ntiles), dim3(KH_ST_THREADS), lds2, st, seq, segs, tiles, nb_alloc, k,
-                           thist, bstart, reinterpret_cast<KmerKey<1>*>(part));
+        const size_t lds2 = kh_extract_staged_lds_bytes(W, nb_alloc);
+        if (W == 1) {
+            allow_lds(k_extract_staged<1>, lds2);
+            hipLaunchKernelGGL(k_extract_staged<1>, dim3(ntiles), dim3(KH_ST_THREADS), lds2, st, seq, segs, tiles,
+                               nb_alloc, k, thist, bstart, reinterpret_cast<KmerKey<1>*>(part));
+        } else {
+            allow_lds(k_extract_staged<2>, lds2);
+            hipLaunchKernelGGL(k_extract_staged<2>, dim3(ntiles), dim3(KH_ST_THREADS), lds2, st, seq, segs, tiles,
+                               nb_alloc, k, thist, bstart, reinterpret_cast<KmerKey<2>*>(part));
+        }
         return;
     }
     const size_t lds = kh_extract_lds_bytes(nb_alloc);

@@ -386,13 +386,16 @@ def test_direct_and_staged_scatter_agree(eng, monkeypatch):
     """pass B has two forms (LDS write combining / direct stores); both must give the same sets."""
     rng = random.Random(321)
     seqs = [random_dna(rng, n, "ACGTN").encode() for n in (200_000, 90_000)]
-    a = eng.build_batch(seqs, 31)
-    monkeypatch.setenv("KHOICE_DIRECT_SCATTER", "1")
-    b = eng.build_batch(seqs, 31)
-    for x, y in zip(a, b):
-        kx, cx = x.download()
-        ky, cy = y.download()
-        assert (kx == ky).all() and (cx == cy).all()
+    seqs.append(random_dna(rng, 700_000).encode())           # several tiles, several staging rounds each
+    for k in (31, 41, 63, 64, 33, 1, 16):                    # one- and two-word keys (staged for both)
+        monkeypatch.delenv("KHOICE_DIRECT_SCATTER", raising=False)
+        a = eng.build_batch(seqs, k)
+        monkeypatch.setenv("KHOICE_DIRECT_SCATTER", "1")
+        b = eng.build_batch(seqs, k)
+        for x, y in zip(a, b):
+            kx, cx = x.download()
+            ky, cy = y.download()
+            assert (kx == ky).all() and (cx == cy).all()
 
 
 def test_exp1_group_waves_equal_single_wave(eng, monkeypatch):
