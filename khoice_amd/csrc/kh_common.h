@@ -143,6 +143,11 @@ constexpr int KH_WORKLIST = 1024;           // keys of out-of-order bins repaire
 constexpr int KH_TABLE_MAX_K = 16;          // direct-addressed occurrence table: 4^16 cells at most
 constexpr int KH_MAX_INPUT_SETS = 128;      // fan-in of one set-operation launch
 constexpr int KH_LHIST_BINS = 512;          // LDS histogram bins fused into set-ops
+#ifndef KH_TUNE_HASH_ROUNDS
+#define KH_TUNE_HASH_ROUNDS 3
+#endif
+constexpr int KH_HASH_ROUNDS = KH_TUNE_HASH_ROUNDS;   // probes in the main LDS hash table before a key moves to the second one
+constexpr int KH_TAG_OVF = 512;             // entries of the tagged union's second table
 
 enum KhSetOp : int {
     KH_OP_UNION = 0,             // n-ary or binary union, counters combined by `mode`

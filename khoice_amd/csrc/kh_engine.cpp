@@ -363,6 +363,15 @@ static void report_stamps(kh_ctx* c, const char* what, DevBuf* sb, u64 nparts) {
         tmin = std::min(tmin, t[0]);
         tmax = std::max(tmax, t[8]);
     }
+    {   // optional finer stamps 9..11 inside the phase between stamps 4 and 5
+        double s9 = 0, s10 = 0, s11 = 0; u64 c9 = 0;
+        for (u64 q = 0; q < nparts; ++q) {
+            const u64* t = &h[q * 16];
+            if (!t[4] || !t[9] || !t[10] || !t[11] || !t[5]) continue;
+            ++c9; s9 += (double)(t[9] - t[4]); s10 += (double)(t[10] - t[9]); s11 += (double)(t[11] - t[10]);
+        }
+        if (c9) fprintf(stderr, "[stamps] %s inside 4-5: first-probe %.0f rounds %.0f stores %.0f (then barrier)\n", what, s9 / c9, s10 / c9, s11 / c9);
+    }
     fprintf(stderr, "[stamps] %s parts=%llu span=%.0f cyc | load %.0f count %.0f scan %.0f scatter %.0f insert %.0f walk1 %.0f lookback %.0f walk2 %.0f\n",
             what, (unsigned long long)cnt, (double)(tmax - tmin), sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt,
             sum[5] / cnt, sum[6] / cnt, sum[7] / cnt, sum[8] / cnt);
@@ -458,7 +467,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         const u64 target = std::max<u64>(16, std::min<u64>((u64)grid->cap * 92 / 100, (u64)(x * x)));
         const u64 per_bucket = (total_pos + grid_nb - 1) / grid_nb;       // keys of one bucket over all genomes
         grid->S = (u32)std::max<u64>(1, (per_bucket + target - 1) / target);
-        if (grid->S > 4096 || grid_nb * grid->S > 0x7fffffffull)
+        if (grid->S > (u32)KH_FINE_BINS / 2 || grid_nb * grid->S > 0x7fffffffull)
             return kh_fail(KH_E_ARG, "grid build: %llu sub-ranges per bucket", (unsigned long long)grid->S);
         grid->c = c;
         grid->nb = (u32)grid_nb;
@@ -1524,6 +1533,7 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     job.ctl = reinterpret_cast<u32*>(wsp + 8 * hist_words);
     job.nb = gb.nb; job.S = gb.S; job.nops = (u32)nseq; job.nbins = nbins; job.abase = abase;
     job.ngroups = (u32)ngroups; job.reps = reps;
+    job.binmul = (1u << 26) / ((KH_FINE_BINS + gb.S - 1) / gb.S);
     job.out_keys = emit ? okeys->p : nullptr;
     job.out_counts = emit ? reinterpret_cast<u32*>(ocnt->p) : nullptr;
     job.desc = emit ? reinterpret_cast<u64*>(wsp + 8 * hist_words + 40 + 256) : nullptr;

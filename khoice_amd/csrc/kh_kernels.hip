@@ -706,10 +706,15 @@ __device__ __forceinline__ void distribute_clear(u32* bins, u32* dirty, u32* scr
     if (tid == 0) scratch[20] = 0;   // work-list length
 }
 
-template <int W, bool PAY, int E>
-__device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E], const u32 n,
-                                KmerKey<W>* s, u32* pay, u32* bins, u32* dirty, u32* wl,
-                                u32* scratch, int k, u32 nslots, u32 q) {
+// Phases 1-3 of the distribution sort: count the keys into the fine bins (the returning LDS add
+// hands every key its arrival rank inside its bin), scan the bins, scatter the keys.  On return
+// (a barrier has been passed) s[] holds the keys grouped by fine bin, in arrival order inside a
+// bin; fr[e] = bin << 16 | arrival rank, at[e] = position of element e, bmax = fullest bin.
+// `binfn(key)` must be monotone in the key over the slot and < KH_FINE_BINS.
+template <int W, bool PAY, int E, class BF>
+__device__ __forceinline__ void distribute_place(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E], const u32 n,
+                                                 KmerKey<W>* s, u32* pay, u32* bins, u32* scratch, BF binfn, u32 q,
+                                                 u32 (&fr)[E], u32 (&at)[E], u32& vmask, u32& bmax) {
     // precondition: distribute_clear() ran and a barrier followed (the kernels fold it into the
     // barrier that broadcasts the ticket)
     constexpr u32 NT = KH_SORT_THREADS;
@@ -719,13 +724,12 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
     // Every phase below is written as "issue all LDS operations of the thread, then consume":
     // used inside one predicated block, a result makes hipcc wait (lgkmcnt(0)) before the next
     // block, which chains the E LDS latencies of a thread instead of overlapping them.
-    u32 fr[E];   // fine bin << 16 | arrival rank inside the bin
-    u32 vmask = 0;   // bit e: element e*NT + tid exists
+    vmask = 0;   // bit e: element e*NT + tid exists
     {
         u32 old[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            fr[e] = fine_bin<W>(kreg[e], k, nslots);
+            fr[e] = binfn(kreg[e]);
             old[e] = 0;
             if ((u32)e * NT + tid < n) {
                 vmask |= 1u << e;
@@ -751,7 +755,8 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
     mx = wave_scan_max(mx);                      // the wave's maximum arrives in lane 63
     if (lane == KH_WAVE - 1) { scratch[wid] = incl; scratch[8 + wid] = mx; }
     __syncthreads();
-    u32 wbase = 0, bmax = 0;
+    u32 wbase = 0;
+    bmax = 0;
 #pragma unroll
     for (u32 w = 0; w < NT / KH_WAVE; ++w) {
         wbase += (w < wid) ? scratch[w] : 0u;
@@ -767,7 +772,6 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
     if (tid == NT - 1) bins[WORDS] = run;   // base of the bin past the last one = n
     __syncthreads();
     KH_STAMP(q, 3);
-    u32 at[E];   // position after the scatter
 #pragma unroll
     for (int e = 0; e < E; ++e) at[e] = bin_base(bins, fr[e] >> 16) + (fr[e] & 0xffffu);
 #pragma unroll
@@ -779,6 +783,16 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
     }
     __syncthreads();
     KH_STAMP(q, 4);
+}
+
+template <int W, bool PAY, int E, class BF>
+__device__ void distribute_sort_bf(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E], const u32 n,
+                                   KmerKey<W>* s, u32* pay, u32* bins, u32* dirty, u32* wl,
+                                   u32* scratch, BF binfn, u32 q) {
+    constexpr u32 NT = KH_SORT_THREADS;
+    const u32 tid = threadIdx.x, lane = lane_id();
+    u32 fr[E], at[E], vmask, bmax;
+    distribute_place<W, PAY, E>(kreg, preg, n, s, pay, bins, scratch, binfn, q, fr, at, vmask, bmax);
     if (bmax > (u32)KH_FINE_LIMIT) {
         bitonic_sort_lds<W, PAY>(s, pay, n);
         KH_STAMP(q, 5);
@@ -869,6 +883,14 @@ __device__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E
         __syncthreads();
     }
     KH_STAMP(q, 5);
+}
+
+template <int W, bool PAY, int E>
+__device__ __forceinline__ void distribute_sort(const KmerKey<W> (&kreg)[E], const u32 (&preg)[E], const u32 n,
+                                                KmerKey<W>* s, u32* pay, u32* bins, u32* dirty, u32* wl,
+                                                u32* scratch, int k, u32 nslots, u32 q) {
+    distribute_sort_bf<W, PAY, E>(kreg, preg, n, s, pay, bins, dirty, wl, scratch,
+                                  [=](const KmerKey<W>& key) { return fine_bin<W>(key, k, nslots); }, q);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1007,10 +1029,120 @@ __device__ u64 rle_emit(const KmerKey<W>* s, const u32 n, u16* hstart, u32* tab,
 // of the sorted bucket s[0..n) go to out[0..d) — the bucket's own place, known before the launch,
 // so nothing is waited for — together with the bucket's sub-range index off[0..S].
 // ------------------------------------------------------------------------------------------
+// Sub-range of a key inside its bucket.  Sub-ranges are made of whole fine bins of the bucket
+// (sub-range f = fine bins [kh_first_bin(f), kh_first_bin(f + 1))), so that keys grouped by fine bin
+// are grouped by sub-range too.
 template <int W>
 __device__ __forceinline__ u32 kh_sub(const KmerKey<W>& key, int k, u32 nb, u32 S) {
-    const u32 frac = (u32)((u64)kh_top32(key, k) * (u64)nb);   // position inside the bucket
-    return (u32)(((u64)frac * (u64)S) >> 32);                  // == kh_slot(key, nb * S) - b * S
+    return (fine_bin<W>(key, k, nb) * S) >> KH_FINE_BITS;
+}
+__host__ __device__ __forceinline__ u32 kh_first_bin(u32 f, u32 S) { return (f * (u32)KH_FINE_BINS + S - 1u) / S; }
+
+// In-bin search for the first copy of each of this thread's keys (its "leader") after
+// distribute_place: keys sharing a fine bin sit next to each other in arrival order, equal keys
+// always share a bin, and bins hold a key or two, so a key finds an earlier copy of itself — or
+// learns that it is the first — with one LDS read in nearly every case.  lead[e] = position of the
+// first copy (== at[e] for a leader).  No repair of the in-bin order is needed by callers that
+// only want equal keys to meet.
+template <int W, int E>
+__device__ __forceinline__ void find_leaders(const KmerKey<W> (&kreg)[E], const KmerKey<W>* s, const u32 (&fr)[E],
+                                             const u32 (&at)[E], const u32 vmask, u32 (&lead)[E]) {
+    KmerKey<W> first[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) first[e] = s[at[e] - (fr[e] & 0xffffu)];   // the bin's first arrival (itself for rank 0)
+    u32 pos[E], act = 0;   // act bit e: element e still looks for an earlier copy, next candidate pos[e]
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        lead[e] = at[e];
+        const u32 rk = fr[e] & 0xffffu;
+        pos[e] = at[e] - rk + 1u;
+        if ((vmask & (1u << e)) && rk) {
+            if (key_eq(first[e], kreg[e])) lead[e] = at[e] - rk;
+            else if (rk >= 2u) act |= 1u << e;
+        }
+    }
+    KH_STAMP(0, 9);
+    // The rare keys that are neither first in their bin nor copies of its first key probe on, in
+    // ROUNDS: every round issues one candidate read for each of the thread's searching elements
+    // together (one LDS round trip per round, not one per element and step).
+    while (__builtin_amdgcn_ballot_w64(act != 0)) {
+        KmerKey<W> cand[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) cand[e] = s[(act & (1u << e)) ? pos[e] : 0u];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (act & (1u << e)) {
+                if (key_eq(cand[e], kreg[e])) { lead[e] = pos[e]; act &= ~(1u << e); }
+                else if (++pos[e] >= at[e]) act &= ~(1u << e);
+            }
+        }
+    }
+    KH_STAMP(0, 10);
+}
+
+// Grid mode of pass C for a bucket that fits LDS: place the keys by fine bin, drop every key that
+// has an earlier copy, write the others in position (= fine bin) order where the bucket's input
+// starts, and derive the sub-range index from the bin table.  No in-bin repair: the output is
+// grouped by sub-range, not sorted inside one (its only reader, the tagged union, re-bins it).
+// lbits: 64 u64 words, zeroed (the dirty-bin bitmap of the full sort, cleared by distribute_clear).
+template <int W, int E>
+__device__ void grid_bucket(const KmerKey<W> (&kreg)[E], const u32 n, KmerKey<W>* s, u32* bins, u32* tab,
+                            u32* scratch, u32* lbits, int k, u32 nb, KmerKey<W>* __restrict__ out,
+                            u16* __restrict__ off, const u32 S, unsigned long long* __restrict__ distinct, u32 q) {
+    constexpr u32 NT = KH_SORT_THREADS;
+    const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    u32 fr[E], at[E], vmask, bmax;
+    {
+        u32 none[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) none[e] = 0;
+        distribute_place<W, false, E>(kreg, none, n, s, nullptr, bins, scratch,
+                                      [=](const KmerKey<W>& key) { return fine_bin<W>(key, k, nb); }, q, fr, at,
+                                      vmask, bmax);
+    }
+    {
+        u32 lead[E];
+        find_leaders<W, E>(kreg, s, fr, at, vmask, lead);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if ((vmask & (1u << e)) && lead[e] == at[e]) atomicOr(&lbits[at[e] >> 5], 1u << (at[e] & 31u));
+    }
+    KH_STAMP(q, 11);
+    __syncthreads();
+    KH_STAMP(q, 5);
+    // position-major from here on: element p = e * NT + tid, consecutive lanes = consecutive outputs
+    const unsigned long long* lb64 = reinterpret_cast<const unsigned long long*>(lbits);
+    u32 lr[E], flags = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u64 word = lb64[e * KH_SORT_NW + wid];          // leaders among this wave's 64 positions
+        if (lane == 0) tab[e * KH_SORT_NW + wid] = (u32)__popcll(word);
+        lr[e] = (u32)__popcll(word & ((1ull << lane) - 1ull));
+        flags |= ((word >> lane) & 1ull) ? (1u << e) : 0u;
+    }
+    table_scan<E>(tab);
+    KH_STAMP(q, 6);
+    KH_STAMP(q, 7);
+    const u32 d = tab[E * KH_SORT_NW];
+    {
+        KmerKey<W> cur[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) cur[e] = s[(flags & (1u << e)) ? (u32)e * NT + tid : 0u];
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (flags & (1u << e)) out[tab[e * KH_SORT_NW + wid] + lr[e]] = cur[e];
+    }
+    // off[f] = leaders in front of the first fine bin of sub-range f
+    for (u32 t = tid; t <= S; t += NT) {
+        u32 v = d;
+        if (t < S) {
+            const u32 P = bin_base(bins, kh_first_bin(t, S));
+            if (P < n) v = tab[P >> 6] + (u32)__popcll(lb64[P >> 6] & ((1ull << (P & 63u)) - 1ull));
+        }
+        off[t] = (u16)v;
+    }
+    if (tid == 0 && d) atomicAdd(distinct, (unsigned long long)d);
+    KH_STAMP(q, 8);
 }
 
 template <int W, int E>
@@ -1128,13 +1260,14 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         KH_STAMP(q, 1);
-        distribute_sort<W, false, E>(kreg, preg, n, s, nullptr, reinterpret_cast<u32*>(hstart),
-                                     tab + 128, tab + 128 + KH_FINE_BINS / 32, scratch, k, seg_nb, q);
         if (grid.off) {
-            grid_emit<W, E>(s, n, tab, out_keys - wk.out_base + lo, grid.off + (u64)wk.gb * (grid.S + 1), grid.S,
-                            k, seg_nb, grid.distinct + wk.gb / grid.nb);
+            grid_bucket<W, E>(kreg, n, s, reinterpret_cast<u32*>(hstart), tab, scratch, tab + 128, k, seg_nb,
+                              out_keys - wk.out_base + lo, grid.off + (u64)wk.gb * (grid.S + 1), grid.S,
+                              grid.distinct + wk.gb / grid.nb, q);
             return;
         }
+        distribute_sort<W, false, E>(kreg, preg, n, s, nullptr, reinterpret_cast<u32*>(hstart),
+                                     tab + 128, tab + 128 + KH_FINE_BINS / 32, scratch, k, seg_nb, q);
         auto eval = [&](u32 h0, u32 h1) -> u32 {
             const u32 c = h1 - h0;
             return (c >= ci && c <= cx) ? c : 0u;
@@ -1583,12 +1716,15 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_uni
     KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
     u32* pay = reinterpret_cast<u32*>(lds_raw + L.pay_off());
     u16* hstart = reinterpret_cast<u16*>(lds_raw + L.hstart_off());
-    u32* ginfo = reinterpret_cast<u32*>(lds_raw + L.lhist_off());              // [64], in the lhist region
+    // Carve (kh_tag_lds_bytes).  Sorting forms: the sort's carve, ginfo[64] in its lhist region, then
+    // the compact histogram hstripe[nbins][8] (8 copies per bin, copy = lane & 7).  Hash-set form
+    // (one-word keys, nothing emitted): 4096 x {key, mask} | ginfo[64] | scratch[32] | hstripe |
+    // second table [KH_TAG_OVF] x {key, mask}.
+    constexpr bool HASHED = !EMIT && W == 1;
+    u32* ginfo = reinterpret_cast<u32*>(lds_raw + (HASHED ? (size_t)65536 : L.lhist_off()));
     u32* tab = reinterpret_cast<u32*>(lds_raw + L.tab_off());
-    u32* scratch = reinterpret_cast<u32*>(lds_raw + L.scratch_off());
-    // compact histogram, 8 copies per bin (copy = lane & 7).  It lives across the slots a
-    // workgroup walks, so it has a carve of its own behind the sort's (kh_tag_lds_bytes).
-    u32* hstripe = reinterpret_cast<u32*>(lds_raw + L.total());                // [nbins][8]
+    u32* scratch = reinterpret_cast<u32*>(lds_raw + (HASHED ? (size_t)65536 + 256 : L.scratch_off()));
+    u32* hstripe = reinterpret_cast<u32*>(lds_raw + (HASHED ? (size_t)65536 + 256 + 128 : L.total()));   // [nbins][8]
     constexpr int CAPC = W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2;
     constexpr int E = (CAPC + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
     constexpr u32 NT = KH_SORT_THREADS;
@@ -1627,7 +1763,17 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_uni
             sbeg = jb.bstart[gb] + o0;
             len = o1 >= o0 ? o1 - o0 : 0xffffffu;   // a corrupt index reads as "too full", never as a wrap
         }
-        distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
+        if constexpr (!emit && W == 1) {
+            // hash-set form: entries {key = empty, mask = 0}, written while the index loads are in flight
+            uint4* t4 = reinterpret_cast<uint4*>(lds_raw);
+#pragma unroll
+            for (int e = 0; e < E; ++e) t4[(u32)e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+            uint4* o4 = reinterpret_cast<uint4*>(hstripe + ((nbins * 8u + 3u) & ~3u));
+            for (u32 i = tid; i < (u32)KH_TAG_OVF; i += NT) o4[i] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+            if (tid == 0) *reinterpret_cast<unsigned long long*>(scratch + 24) = 0ull;
+        } else {
+            distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
+        }
         const u32 incl = wave_scan_add(len);
         const u32 n64 = (u32)__builtin_amdgcn_readlane((int)incl, KH_WAVE - 1);
         u32 n = 0;
@@ -1672,100 +1818,174 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_uni
                 preg[e] = ga;
             }
         }
-        __syncthreads();   // bins cleared; the previous slot's readers of s / pay are done
+        __syncthreads();   // bins cleared
 #ifdef KH_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         KH_STAMP(r, 1);
-        distribute_sort<W, true, E>(kreg, preg, n, s, pay, reinterpret_cast<u32*>(hstart), tab + 128,
-                                    tab + 128 + KH_FINE_BINS / 32, scratch, k, nslots, r);
-        // ---- a run of equal keys -> genome mask -> per-group counts + number of groups
-        auto eval = [&](u32 h0, u32 h1) -> u32 {
-            u64 mask = 0;
-            for (u32 t = h0; t < h1; ++t) mask |= 1ull << (pay[t] & 63u);
+        // fine bin of a key inside this slot: the slot is fine bins [fb0, fb0 + width) of bucket b
+        // (kh_first_bin), i.e. positions [fb0 << 19, ...) of the bucket's 32-bit position scale;
+        // binmul stretches the widest slot over the KH_FINE_BINS bins.  A key from outside the slot
+        // (corrupt index) lands in the last bin instead of outside the table.
+        const u32 rel0 = kh_first_bin(f, S) << (32 - KH_FINE_BITS);
+        const u32 binmul = jb.binmul;
+        auto binfn = [=](const KmerKey<W>& key) -> u32 {
+            const u32 frac = (u32)((u64)kh_top32(key, k) * (u64)nb);
+            const u32 fb = (u32)(((u64)(frac - rel0) * (u64)binmul) >> 32);
+            return fb < (u32)KH_FINE_BINS ? fb : (u32)KH_FINE_BINS - 1u;
+        };
+        // a genome mask -> per-group counts (step_4 bins) + number of groups (returned)
+        auto eval_mask = [&](u64 mask, u32 g) -> u32 {
             u32 ng = 0;
-            while (mask) {
-                const u32 gi = ginfo[__ffsll((unsigned long long)mask) - 1];
-                const u32 g0 = gi & 0xffu, gn = (gi >> 8) & 0xffu, bin0 = gi >> 16;
+            while (true) {
+                const u32 g0 = g & 0xffu, gn = (g >> 8) & 0xffu, bin0 = g >> 16;
                 const u64 gm = (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0;
                 u32 c = (u32)__popcll(mask & gm);
                 c = c < cs ? c : cs;
                 atomicAdd(&hstripe[(bin0 + c) * 8u + (lane & 7u)], 1u);
                 mask &= ~gm;
                 ++ng;
+                if (!mask) break;
+                g = ginfo[__ffsll((unsigned long long)mask) - 1];
             }
             return ng < cs ? ng : cs;
         };
-        if constexpr (!emit) {
-            // Nothing is written, so after the run heads are known the key array is free: it
-            // becomes one 64-bit genome mask per run, filled key-parallel with LDS atomics (no
-            // thread walks a run: a walk is a chain of dependent LDS reads).
-            const u64 le_mask = (2ull << lane) - 1ull;
-            const u32 wid = tid >> 6;
-            u32 rid[E], pv[E];
-            {
-                KmerKey<W> cur[E], prv[E];
+        if constexpr (!emit && W == 1) {
+            // Nothing is written, so nothing has to be sorted — equal keys only have to MEET.  One-word
+            // keys meet in an LDS hash set: 4096 entries {key, genome mask} over the sort's key +
+            // payload + bin-table carve, home entry = the key's fine bin / 2 (keys are uniform inside
+            // the slot, so this order-preserving "hash" spreads them evenly), linear probing.  A 64-bit
+            // compare-and-swap either claims an empty entry or returns the key that lives there: one
+            // LDS round trip tells a key where its first copy is, and its genome bit is ORed in there.
+            // No counting, no scan, no scatter, no search: three phases instead of a dozen.
+            constexpr u32 T = 4096, T2 = KH_TAG_OVF;
+            constexpr u64 EMPTY = ~0ull;
+            struct alignas(16) Ent { unsigned long long key, mask; };
+            Ent* tbl = reinterpret_cast<Ent*>(lds_raw);
+            Ent* ovf = reinterpret_cast<Ent*>(hstripe + ((nbins * 8u + 3u) & ~3u));               // [T2], behind the histogram
+            unsigned long long* special = reinterpret_cast<unsigned long long*>(scratch + 24);   // mask of the key ~0
+            // (both tables were initialised while the key loads were in flight, see above)
+            // Linear probing has long clusters (max ~30 entries at this load) and the whole workgroup
+            // would wait for the one wave that walks the longest: a key gets KH_HASH_ROUNDS probes in the
+            // main table, then moves to a small second table with an independent hash.  Occupied
+            // entries stay occupied, so every copy of a key takes the same decisions as the first.
+            u32 slot[E], act = 0;
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const u32 i = (u32)e * NT + tid;
-                    cur[e] = s[i < n ? i : 0];
-                    prv[e] = s[(i < n && i) ? i - 1 : 0];
-                    pv[e] = pay[i < n ? i : 0];
-                }
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const u32 i = (u32)e * NT + tid;
-                    const bool head = (i < n) && (i == 0 || !key_eq(cur[e], prv[e]));
-                    const u64 bal = __ballot(head);
-                    if (lane == 0) tab[e * KH_SORT_NW + wid] = (u32)__popcll(bal);
-                    rid[e] = (u32)__popcll(bal & le_mask);   // heads of this wave's pass up to and including this lane
+            for (int e = 0; e < E; ++e) {
+                slot[e] = binfn(kreg[e]) >> (KH_FINE_BITS - 12);
+                if ((u32)e * NT + tid < n) {
+                    if (kreg[e].lo == EMPTY) atomicOr(special, 1ull << (preg[e] & 63u));
+                    else act |= 1u << e;
                 }
             }
-            table_scan<E>(tab);   // its first barrier also ends every read of the keys
+            // (two copies of the probe loop rather than a lambda: capturing `act` by reference put it on the stack)
+#define KH_PROBE_ROUNDS(TBL, TMASK, ROUNDS)                                                                           \
+            for (u32 round = 0; round < (ROUNDS) && __builtin_amdgcn_ballot_w64(act != 0); ++round) {                \
+                unsigned long long old[E];                                                                            \
+                _Pragma("unroll") for (int e = 0; e < E; ++e)                                                         \
+                    old[e] = (act & (1u << e)) ? atomicCAS(&(TBL)[slot[e]].key, EMPTY, (unsigned long long)kreg[e].lo) : 0ull; \
+                _Pragma("unroll") for (int e = 0; e < E; ++e) {                                                       \
+                    if (act & (1u << e)) {                                                                            \
+                        if (old[e] == EMPTY || old[e] == kreg[e].lo) {                                                \
+                            atomicOr(&(TBL)[slot[e]].mask, 1ull << (preg[e] & 63u));                                  \
+                            act &= ~(1u << e);                                                                        \
+                        } else {                                                                                      \
+                            slot[e] = (slot[e] + 1u) & (TMASK);                                                       \
+                        }                                                                                             \
+                    }                                                                                                 \
+                }                                                                                                     \
+            }
+            KH_PROBE_ROUNDS(tbl, T - 1u, (u32)KH_HASH_ROUNDS)
+            if (__builtin_amdgcn_ballot_w64(act != 0)) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) slot[e] = (u32)((kreg[e].lo * KH_C3) >> 40) & (T2 - 1u);
+                KH_PROBE_ROUNDS(ovf, T2 - 1u, T2)
+                // second table full of other keys (a slot of nearly all-distinct keys): on in the main
+                // table from where the first level stopped — slow, never wrong (a full table stays full)
+                if (__builtin_amdgcn_ballot_w64(act != 0)) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        slot[e] = ((binfn(kreg[e]) >> (KH_FINE_BITS - 12)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
+                    KH_PROBE_ROUNDS(tbl, T - 1u, T)
+                    if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(lb.err, KH_ERR_CAPACITY);
+                }
+            }
+#undef KH_PROBE_ROUNDS
+            __syncthreads();
+            KH_STAMP(r, 5);
             KH_STAMP(r, 6);
-            const u32 d = tab[E * KH_SORT_NW];
-            unsigned long long* rmask = reinterpret_cast<unsigned long long*>(s);
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const u32 r0 = (u32)e * NT + tid;
-                if (r0 < d) rmask[r0] = 0ull;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const u32 i = (u32)e * NT + tid;
-                if (i < n) atomicOr(&rmask[tab[e * KH_SORT_NW + wid] + rid[e] - 1u], 1ull << (pv[e] & 63u));
-            }
-            __syncthreads();
             KH_STAMP(r, 7);
+            // every occupied entry is one distinct key of the slot
             u64 mk[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const u32 r0 = (u32)e * NT + tid;
-                mk[e] = r0 < d ? rmask[r0] : 0ull;
+                const Ent en = tbl[(u32)e * NT + tid];
+                mk[e] = en.key != EMPTY ? en.mask : 0ull;
             }
-            // first group of every run (nearly always the only one): table reads issued together
-            u32 gi[E];
+            u32 gi[E];   // first group of every mask (nearly always the only one): table reads issued together
 #pragma unroll
             for (int e = 0; e < E; ++e) gi[e] = ginfo[mk[e] ? __ffsll((unsigned long long)mk[e]) - 1 : 0];
-            u32 ones = 0;   // runs that sit in exactly one group
+            u32 ones = 0;   // keys that sit in exactly one group
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                u64 mask = mk[e];
-                if (!mask) continue;
-                u32 ng = 0, g = gi[e];
-                while (true) {
-                    const u32 g0 = g & 0xffu, gn = (g >> 8) & 0xffu, bin0 = g >> 16;
-                    const u64 gm = (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0;
-                    u32 c = (u32)__popcll(mask & gm);
-                    c = c < cs ? c : cs;
-                    atomicAdd(&hstripe[(bin0 + c) * 8u + (lane & 7u)], 1u);
-                    mask &= ~gm;
-                    ++ng;
-                    if (!mask) break;
-                    g = ginfo[__ffsll((unsigned long long)mask) - 1];
+                if (!mk[e]) continue;
+                const u32 ng = eval_mask(mk[e], gi[e]);
+                if (ng == 1u) ++ones;
+                else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
+            }
+            for (u32 i = tid; i < T2; i += NT) {   // keys that moved to the second table (a few per slot)
+                const Ent en = ovf[i];
+                if (en.key != EMPTY) {
+                    const u32 ng = eval_mask(en.mask, ginfo[__ffsll((unsigned long long)en.mask) - 1]);
+                    if (ng == 1u) ++ones;
+                    else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
                 }
-                ng = ng < cs ? ng : cs;
+            }
+            if (tid == 0 && *special) {   // the one key that cannot live in the table (all bits set, k = 32 only)
+                const u64 m = *special;
+                const u32 ng = eval_mask(m, ginfo[__ffsll((unsigned long long)m) - 1]);
+                if (ng == 1u) ++ones;
+                else atomicAdd(&hstripe[(jb.abase + ng) * 8u], 1u);
+            }
+            // the across-group bin "1" would otherwise take one LDS atomic per key: per-wave sum
+            ones = wave_scan_add(ones);
+            if (lane == KH_WAVE - 1 && ones) atomicAdd(&hstripe[(jb.abase + 1u) * 8u], ones);
+            __syncthreads();
+            KH_STAMP(r, 8);
+        } else if constexpr (!emit) {
+            // Nothing is written, so nothing has to be sorted: equal keys share a fine bin, every
+            // key finds the first copy of itself there (find_leaders) and ORs its genome bit into
+            // that copy's 64-bit mask.  The masks overlay the payload + bin-table carve (both free
+            // once the keys are placed); tags stay in registers.
+            u32 fr[E], at[E], vmask, bmax;
+            distribute_place<W, false, E>(kreg, preg, n, s, nullptr, reinterpret_cast<u32*>(hstart), scratch, binfn,
+                                          r, fr, at, vmask, bmax);
+            unsigned long long* rmask = reinterpret_cast<unsigned long long*>(pay);
+            u32 lead[E];
+            find_leaders<W, E>(kreg, s, fr, at, vmask, lead);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((vmask & (1u << e)) && lead[e] == at[e]) rmask[at[e]] = 1ull << (preg[e] & 63u);
+            KH_STAMP(r, 11);
+            __syncthreads();
+            KH_STAMP(r, 5);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((vmask & (1u << e)) && lead[e] != at[e]) atomicOr(&rmask[lead[e]], 1ull << (preg[e] & 63u));
+            __syncthreads();
+            KH_STAMP(r, 6);
+            KH_STAMP(r, 7);
+            u64 mk[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) mk[e] = ((vmask & (1u << e)) && lead[e] == at[e]) ? rmask[at[e]] : 0ull;
+            u32 gi[E];   // first group of every mask (nearly always the only one): table reads issued together
+#pragma unroll
+            for (int e = 0; e < E; ++e) gi[e] = ginfo[mk[e] ? __ffsll((unsigned long long)mk[e]) - 1 : 0];
+            u32 ones = 0;   // keys that sit in exactly one group
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (!mk[e]) continue;
+                const u32 ng = eval_mask(mk[e], gi[e]);
                 if (ng == 1u) ++ones;
                 else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
             }
@@ -1775,6 +1995,14 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_uni
             __syncthreads();
             KH_STAMP(r, 8);
         } else {
+            // the across-group set is written (multi-GPU exchange): full sort, ordered output
+            distribute_sort_bf<W, true, E>(kreg, preg, n, s, pay, reinterpret_cast<u32*>(hstart), tab + 128,
+                                           tab + 128 + KH_FINE_BINS / 32, scratch, binfn, r);
+            auto eval = [&](u32 h0, u32 h1) -> u32 {
+                u64 mask = 0;
+                for (u32 t = h0; t < h1; ++t) mask |= 1ull << (pay[t] & 63u);
+                return eval_mask(mask, ginfo[__ffsll((unsigned long long)mask) - 1]);
+            };
             auto sink = [&](u64 o, const KmerKey<W>& key, u32 c) {
                 out_keys[o] = key;
                 out_counts[o] = c;
@@ -2029,11 +2257,15 @@ void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
     }
 }
 
-size_t kh_tag_lds_bytes(int W, u32 cap, u32 nbins) { return kh_sort_lds_bytes(W, cap, true) + (size_t)nbins * 32; }
+size_t kh_tag_lds_bytes(int W, u32 cap, u32 nbins, bool emit) {
+    const size_t hist = ((size_t)nbins * 32 + 15) & ~(size_t)15;
+    if (W == 1 && !emit) return (size_t)65536 + 256 + 128 + hist + (size_t)KH_TAG_OVF * 16;   // hash-set form
+    return kh_sort_lds_bytes(W, cap, true) + hist;
+}
 void kh_launch_union_tagged(int W, const KhTagJob& job, u32 grid, int k, u32 cs, hipStream_t st) {
     if (!grid) return;
     const u32 cap = W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2;
-    const size_t lds = kh_tag_lds_bytes(W, cap, job.nbins);
+    const size_t lds = kh_tag_lds_bytes(W, cap, job.nbins, job.desc != nullptr);
 #define KH_UT(WW, EE)                                                                                   \
     do {                                                                                                \
         allow_lds(k_union_tagged<WW, EE>, lds);                                                         \

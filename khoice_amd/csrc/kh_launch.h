@@ -102,6 +102,7 @@ struct KhTagJob {
     unsigned long long* hist;   // [reps][nbins]
     u32* ctl;                   // [0] error bits, [1] fullest slot seen
     u32 nb, S, nops, nbins, abase, ngroups, reps;
+    u32 binmul;                 // 2^26 / (fine bins of the widest sub-range): in-slot fine-bin scale
     // optional ordered output (multi-GPU: the local across-group set, counter = groups holding the key)
     void* out_keys;
     u32* out_counts;
@@ -138,7 +139,7 @@ void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
                            u32 nbuckets, int k,
                            void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
                            const KhGrid& grid, hipStream_t st);
-size_t kh_tag_lds_bytes(int W, u32 cap, u32 nbins);
+size_t kh_tag_lds_bytes(int W, u32 cap, u32 nbins, bool emit);
 void kh_launch_union_tagged(int W, const KhTagJob& job, u32 grid, int k, u32 cs, hipStream_t st);
 void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges, int k,
                             u64* bounds, u64* zero, u64 zero_words, hipStream_t st);

@@ -118,3 +118,17 @@ def test_fused_full_size_genomes(eng):
     seqs = [t for _, _, t in items]
     group_of = [s - 1 for s, _, _ in items]
     check(eng, seqs, group_of, 31)
+
+
+def test_fused_all_ones_key(eng):
+    """k = 32: the mixed key with all 64 bits set cannot live in the hash sets (it is their empty
+    marker) and is carried beside them.  Find the k-mer that mixes to it and plant it."""
+    from khoice_amd import engine as E
+    k = 32
+    raw = int(E.unmix_host(k, np.array([0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0])
+    kmer = "".join("ACGT"[(raw >> (2 * (k - 1 - i))) & 3] for i in range(k))
+    rng = random.Random(5)
+    a = random_dna(rng, 5000) + "N" + kmer + "N" + random_dna(rng, 5000)
+    b = random_dna(rng, 4000) + "N" + kmer
+    c = random_dna(rng, 3000)
+    check(eng, [a.encode(), b.encode(), c.encode(), (kmer + "N" + kmer).encode()], [0, 0, 1, 1], k, hist_len=16)
