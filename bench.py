@@ -42,8 +42,21 @@ def parse_args():
     ap.add_argument("--length", type=int, default=5_000_000)
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-species", type=int, default=4)
+    ap.add_argument("--cpu-species", type=int, default=0, help="species in the CPU baseline sample (0 = all)")
     return ap.parse_args()
+
+
+def source_hash() -> str:
+    """sha256 over the kernel / engine sources: ties a PMC traffic file to the code it was measured on
+    (the GPU box has no .git to ask)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "khoice_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def kernel_algorithmic_bytes(name, st, k, nseq_bases):
@@ -191,15 +204,22 @@ def main():
     avg_ms = kern[hot]["ms"] / max(1, kern[hot]["launches"])
     alg_bytes = kernel_algorithmic_bytes(hot, st, args.k, total_bases)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch from the PMC passes (tools/collect_profiles.sh): only when that file was
+    # collected on exactly these sources, otherwise null + traffic_stale
+    traffic, traffic_stale = None, False
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(hot, {}).get("bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("_source_sha") == source_hash():
+                traffic = tj.get(hot, {}).get("bytes_per_launch")
+            else:
+                traffic_stale = True
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": hot, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_stale": traffic_stale,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)}
     # whole K1 build against SURVEY §8d's compulsory figure N*1 + D*(8W+4)
     w = 1 if args.k <= 32 else 2
@@ -216,6 +236,12 @@ def main():
     v_total = int(res["across_hist"][1:].sum()) if res.get("across_hist") is not None else 0
     path_bytes = total_bases + u_total * (8 * w + 4) + u_total * 8 * w + v_total * (8 * w + 4)
     path_gbs = path_bytes / (ms_per_step * 1e-3) / 1e9
+    path_roofline = None
+    if world == 1:      # (at N > 1 the across-group histogram is global, the other terms per rank)
+        path_roofline = {"bound": "hbm", "algorithmic_bytes_per_step": int(path_bytes),
+                         "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(path_gbs / HBM_PEAK_GBS, 4),
+                         "formula": "bases + U(8W+4) + U*8W + V(8W+4), SURVEY 8d"}
 
     out = {
         "metric": "distinct k-mers/sec (k=31, canonical)" if args.k == 31 else f"distinct k-mers/sec (k={args.k}, canonical)",
@@ -234,33 +260,51 @@ def main():
                               "achieved": round(k1_bytes / (k1_ms * 1e-3) / 1e9, 1) if k1_ms else 0.0,
                               "frac": round(k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k1_ms else 0.0,
                               "unit": "GB/s"},
-        "path_roofline": {"bound": "hbm", "algorithmic_bytes_per_step": int(path_bytes),
-                          "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(path_gbs / HBM_PEAK_GBS, 4),
-                          "formula": "bases + U(8W+4) + U*8W + V(8W+4), SURVEY 8d"},
+        "path_roofline": path_roofline,
         "kernel_ms_per_step": kernel_ms,
         "replans": st["retries"], "order_fallbacks": st.get("order_fallbacks", 0),
         "setup_seconds": round(gen_s, 1),
     }
 
-    # ---- CPU baseline: the C restatement on a bounded sample of the same workload
+    # ---- CPU baseline: the C restatement (oracle/kh_oracle.c, kho_exp1) on the host cores.
+    # All threads (genomes in parallel, surplus threads inside the radix passes) on the whole
+    # workload, and ONE thread on one species of it; both checked against the GPU histograms.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import c_oracle as CO
-        ns = min(args.cpu_species, args.species)
-        sample = [(s, g, t) for s, g, t in items if s - 1 - rank * args.species < ns]
+        ns = args.species if args.cpu_species <= 0 else min(args.cpu_species, args.species)
+        sample = [(s, g, t) for s, g, t in items if s - 1 < ns]
         cseqs = [t for _, _, t in sample]
-        cgroup = [s - 1 - rank * args.species for s, _, _ in sample]
-        cores = min(os.cpu_count() or 1, len(cseqs))
+        cgroup = [s - 1 for s, _, _ in sample]
+        cores = os.cpu_count() or 1
         c0 = time.perf_counter()
         cres = CO.exp1(cseqs, cgroup, args.k, cs=5000, hist_len=5001, nthreads=cores)
         cdt = time.perf_counter() - c0
         cd = int(cres["distinct_per_seq"].sum())
         ok = bool((cres["within_hist"] == res["within_hist"][:ns]).all())
+        ok_across = bool((cres["across_hist"] == res["across_hist"]).all()) if ns == args.species else None
+        one = [(s, g, t) for s, g, t in items if s == 1]
+        o0 = time.perf_counter()
+        ores = CO.exp1([t for _, _, t in one], [0] * len(one), args.k, cs=5000, hist_len=5001, nthreads=1)
+        odt = time.perf_counter() - o0
+        od = int(ores["distinct_per_seq"].sum())
+        model = ""
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
         out["cpu_baseline"] = {"value": round(cd / cdt, 1), "unit": "distinct k-mers/s",
-                               "cores": int(cres["threads"]), "kind": "port",
-                               "sample": f"{ns} species x {args.genomes} genomes x {args.length} bp of the same "
-                                         f"set, oracle/kh_oracle.c kho_exp1, {cdt:.1f} s",
-                               "within_hist_equal_to_gpu": ok}
+                               "cores": int(cres["threads"]), "kind": "port", "cpu_model": model,
+                               "sample": f"{ns} species x {args.genomes} genomes x {args.length} bp "
+                                         f"({'the whole workload' if ns == args.species else 'of the same set'}), "
+                                         f"oracle/kh_oracle.c kho_exp1, {cdt:.1f} s",
+                               "one_thread": {"value": round(od / odt, 1), "cores": 1,
+                                              "sample": f"species 1 ({len(one)} genomes), {odt:.1f} s",
+                                              "within_hist_equal_to_gpu":
+                                                  bool((ores["within_hist"][0] == res["within_hist"][0]).all())},
+                               "within_hist_equal_to_gpu": ok, "across_hist_equal_to_gpu": ok_across}
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()

@@ -161,8 +161,7 @@ uint32_t hist_lines(const kh_set* s) {
     kh_set_counter_max(s, &cm);
     if (cm <= 0xffu) return 0xffu;
     if (cm <= 0xffffu) return 0xffffu;
-    if (cm <= 0xffffffu) return 0xffffffu;
-    return 0xfffffffeu;
+    return 0xffffffu;   // counters saturated above three bytes: the histogram stops at 2^24 - 1 lines
 }
 
 struct Cut { uint32_t ci = 1, cx = KH_NO_MAX, cs = 0; int mode = -1; };
@@ -251,7 +250,13 @@ int do_simple(const std::vector<std::string>& a) {
         const std::string out = a[i++];
         const Cut c = take_opts(a, i);
         no_cutoffs(c, "simple output");
-        const uint32_t cs = c.cs ? c.cs : KH_KMC_DEFAULT_CS;
+        // no -cs on the output: the operands' larger counter range (PARITY UNPINNED — no KMC binary or
+        // fixture to check against; the reference's `simple ... intersect OUT -ocsum` calls,
+        // exp_type_2.smk:363-365, run on a -cs5000 group union and would saturate at 255 otherwise)
+        uint32_t cma = KH_KMC_DEFAULT_CS, cmb = KH_KMC_DEFAULT_CS;
+        kh_set_counter_max(A.h, &cma);
+        kh_set_counter_max(B.h, &cmb);
+        const uint32_t cs = c.cs ? c.cs : std::max(cma, cmb);
         int code, mode;
         const kh_set *x = A.h, *y = B.h;
         if (op == "intersect") { code = KH_INTERSECT; mode = KH_MODE_MIN; }
@@ -312,14 +317,27 @@ struct Parser {
         while (peek("*")) { ++at; auto n = std::make_unique<Expr>(); n->op = '*'; n->kids.push_back(std::move(l)); n->kids.push_back(factor()); l = std::move(n); }
         return l;
     }
-    std::unique_ptr<Expr> expr() {
+    // KMC binds '*' tightest, then '-' and '~', then '+' (khoice only ever writes '+')
+    std::unique_ptr<Expr> diff() {
         auto l = term();
-        while (peek("+") || peek("-") || peek("~")) {
+        while (peek("-") || peek("~")) {
             const char op = tok[at++][0];
-            auto r = term();
-            if (op == '+' && l->op == '+') { l->kids.push_back(std::move(r)); continue; }   // n-ary union
             auto n = std::make_unique<Expr>();
             n->op = op;
+            n->kids.push_back(std::move(l));
+            n->kids.push_back(term());
+            l = std::move(n);
+        }
+        return l;
+    }
+    std::unique_ptr<Expr> expr() {
+        auto l = diff();
+        while (peek("+")) {
+            ++at;
+            auto r = diff();
+            if (l->op == '+') { l->kids.push_back(std::move(r)); continue; }   // n-ary union
+            auto n = std::make_unique<Expr>();
+            n->op = '+';
             n->kids.push_back(std::move(l));
             n->kids.push_back(std::move(r));
             l = std::move(n);
@@ -373,7 +391,7 @@ int do_complex(const std::vector<std::string>& a) {
     if (!f) die("cannot open " + a[0]);
     std::map<std::string, Set> inputs;
     std::string section, line, out_prefix, expr_text;
-    uint32_t cs = KH_KMC_DEFAULT_CS;
+    uint32_t cs = 0;   // 0: no -cs given -> the largest counter range among the inputs (see do_simple)
     while (std::getline(f, line)) {
         while (!line.empty() && (line.back() == '\r' || isspace((unsigned char)line.back()))) line.pop_back();
         size_t b = 0;
@@ -413,6 +431,14 @@ int do_complex(const std::vector<std::string>& a) {
         }
     }
     if (out_prefix.empty()) die("complex: no OUTPUT: line");
+    if (!cs) {
+        cs = KH_KMC_DEFAULT_CS;
+        for (auto& kv : inputs) {
+            uint32_t cm = KH_KMC_DEFAULT_CS;
+            kh_set_counter_max(kv.second.h, &cm);
+            cs = std::max(cs, cm);
+        }
+    }
     Parser p(expr_text);
     auto e = p.expr();
     if (p.at != p.tok.size()) die("complex: trailing text in expression");
@@ -454,6 +480,9 @@ int kh_cli_kmc_tools(kh_ctx* ctx, const std::vector<std::string>& args, std::str
         else rc = tools_usage(err);
     } catch (const Fail& f) {
         err += "kmc_tools: " + f.msg + "\n";
+        rc = 1;
+    } catch (const std::exception& e) {   // bad_alloc and friends must not take a resident server down
+        err += std::string("kmc_tools: ") + e.what() + "\n";
         rc = 1;
     }
     g_ctx = nullptr;

@@ -812,6 +812,13 @@ static int setop_bounds(SetopJob& j) {
                            reinterpret_cast<u64*>(j.d_bounds->p), reinterpret_cast<u64*>(j.d_lb->p),
                            j.lb_words(), c->st);
     c->prof_end();
+    // Test hook (tests/test_gpu_parity.py::test_corrupt_slot_bounds_fail_closed): plant a slot bound
+    // that lies past the end of operand 0, i.e. the state a broken bounds pass would leave behind.
+    // The set operation must report KH_ERR_ORDER and read nothing through it.
+    if (getenv("KHOICE_DEBUG_CORRUPT_BOUNDS") && j.nranges >= 2) {
+        static const u64 poison = 0x0000ffffffffff00ull;
+        HIPCHK(hipMemcpyAsync(reinterpret_cast<u64*>(j.d_bounds->p) + 1, &poison, 8, hipMemcpyHostToDevice, c->st));
+    }
     return KH_OK;
 }
 
@@ -924,6 +931,9 @@ static int setop_finish(SetopJob& j, kh_set** out) {
     }
     for (int attempt = 0; attempt < 8; ++attempt) {
         const u32 err = reinterpret_cast<const u32*>(&j.tail[1])[1];
+        if (err & KH_ERR_ORDER)
+            return kh_fail(KH_E_ARG, "set operation: an operand is not sorted by mixed key (kh_set_wrap_device and "
+                                     "kh_set_from_device trust their caller on that); nothing was read outside it");
         if (err & KH_ERR_SPIN_TIMEOUT) {
             if (c->dynamic_order) return kh_fail(KH_E_INTERNAL, "look-back spin timed out in set operation");
             c->dynamic_order = true;      // index order did not hold: tickets from now on

@@ -4,6 +4,7 @@
 // (workflow/rules/exp_type_1.smk:160-161,210-212; src/merge_lists.py:19-22).
 #include <hip/hip_runtime.h>
 #include <unistd.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -193,8 +194,28 @@ extern "C" int kh_load(kh_ctx* c, const char* prefix, kh_set** out) {
     if (!fs) return kh_fail(KH_E_IO, "cannot open %s", suf.c_str());
     char magic[8];
     const size_t kb = 8 * (size_t)h.words;
-    std::vector<uint8_t> keys(kb * h.n);
-    std::vector<uint32_t> counts(h.has_counts ? h.n : 0);
+    // the header's record count is checked against the file before anything of that size is
+    // allocated: a truncated or corrupt pair must be an error return, never a bad_alloc thrown
+    // through this extern "C" frame (it would take a resident khoice_server down with it)
+    {
+        struct stat sb;
+        const uint64_t rec = kb + (h.has_counts ? 4 : 0);
+        if (fstat(fileno(fs), &sb) != 0 || (uint64_t)sb.st_size < 8 || h.n > ((uint64_t)sb.st_size - 8) / rec ||
+            (uint64_t)sb.st_size != 8 + h.n * rec) {
+            fclose(fs);
+            return kh_fail(KH_E_FORMAT, "%s is truncated or does not match its header (%llu records expected)",
+                           suf.c_str(), (unsigned long long)h.n);
+        }
+    }
+    std::vector<uint8_t> keys;
+    std::vector<uint32_t> counts;
+    try {
+        keys.resize(kb * h.n);
+        counts.resize(h.has_counts ? h.n : 0);
+    } catch (const std::exception&) {
+        fclose(fs);
+        return kh_fail(KH_E_NOMEM, "%s: not enough host memory for %llu records", suf.c_str(), (unsigned long long)h.n);
+    }
     bool ok = fread(magic, 1, 8, fs) == 8 && memcmp(magic, "KHAMDSUF", 8) == 0;
     ok = ok && (keys.empty() || fread(keys.data(), 1, keys.size(), fs) == keys.size());
     ok = ok && (counts.empty() || fread(counts.data(), 4, counts.size(), fs) == counts.size());
@@ -207,7 +228,11 @@ extern "C" int kh_load(kh_ctx* c, const char* prefix, kh_set** out) {
 // ------------------------------------------------------------------------------ text outputs
 extern "C" int kh_histogram_file(kh_ctx* c, const kh_set* s, uint32_t cmax, const char* path) {
     if (!c || !s || !path || cmax < 1) return kh_fail(KH_E_ARG, "kh_histogram_file: bad argument");
-    std::vector<uint64_t> h((size_t)cmax + 1);
+    // one line per counter value: 2^24 lines (a three-byte counter) is the most this writes; a set
+    // saturated beyond that would mean a text file of gigabytes nobody reads
+    if (cmax > 0xffffffu) return kh_fail(KH_E_ARG, "kh_histogram_file: %u histogram lines requested (limit 16777215)", cmax);
+    std::vector<uint64_t> h;
+    try { h.resize((size_t)cmax + 1); } catch (const std::exception&) { return kh_fail(KH_E_NOMEM, "histogram of %u lines", cmax); }
     int r = kh_histogram(c, s, h.data(), cmax + 1);
     if (r != KH_OK) return r;
     AtomicFile f;

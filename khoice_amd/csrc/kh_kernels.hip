@@ -1464,7 +1464,12 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
         u64 chain_in = (slot0 && have) ? bounds[lane * per + slot0] : 0ull;   // inputs in front of this chain
         // slice lengths are scanned as 32-bit values on the DPP path; a slice of 2^24 records or
         // more is far beyond any slot capacity and only needs to be reported as "too full"
-        const u64 len64 = have ? pre_b1 - pre_b0 : 0ull;
+        // bounds that run backwards or past the operand's end (an operand that is not sorted by
+        // mixed key: kh_set_wrap_device / kh_set_from_device trust their caller) must never reach the
+        // gather: the slot is dropped and KH_ERR_ORDER raised
+        const bool bad_bounds = have && (pre_b1 < pre_b0 || pre_b1 > pre_sv.n);
+        if (__builtin_amdgcn_ballot_w64(bad_bounds) && tid == 0) atomicOr(lb.err, KH_ERR_ORDER);
+        const u64 len64 = (have && !bad_bounds) ? pre_b1 - pre_b0 : (bad_bounds ? 0xffffffffull : 0ull);
         const u32 len = len64 > 0xffffffull ? 0xffffffu : (u32)len64;
         const u32 incl = wave_scan_add(len);
         const u64 n64 = (u32)__builtin_amdgcn_readlane((int)incl, KH_WAVE - 1);
@@ -1559,7 +1564,12 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_set
                 skey[g] = reinterpret_cast<u64>(sv.keys);
                 scnt[g] = reinterpret_cast<u64>(sv.counts);
                 suni[g] = sv.uniform;
-                len = b1 - b0;
+                if (b1 < b0 || b1 > sv.n) {   // see the wave-local form: never a wrapped length
+                    atomicOr(lb.err, KH_ERR_ORDER);
+                    len = 0xffffffffull;
+                } else {
+                    len = b1 - b0;
+                }
             }
             u64 incl = len;
 #pragma unroll
@@ -1762,6 +1772,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_uni
             const u32 o0 = o[0], o1 = o[1];
             sbeg = jb.bstart[gb] + o0;
             len = o1 >= o0 ? o1 - o0 : 0xffffffu;   // a corrupt index reads as "too full", never as a wrap
+            if (o1 < o0) atomicOr(jb.ctl, KH_ERR_ORDER);
         }
         if constexpr (!emit && W == 1) {
             // hash-set form: entries {key = empty, mask = 0}, written while the index loads are in flight

@@ -93,6 +93,17 @@ class EngineOps:
         return self.eng.wrap_device(s.k, hi - lo, keys_ptr + lo * 8 * w,
                                     counts_ptr + lo * 4 if counts_ptr else None, uniform=s.info()["uniform"])
 
+    def export_all(self, s):
+        """(keys int64[n*W], counts int32[n]) device tensors holding the set's raw storage (mixed keys
+        ascending, counters materialised): the send buffer of the exchange.  One copy each; the slices
+        of a sorted set are already destination-major, so nothing is packed."""
+        n, w = len(s), self.words(s.k)
+        keys = torch.empty(n * w, dtype=torch.int64, device=self.device)
+        cnt = torch.empty(n, dtype=torch.int32, device=self.device)
+        if n:
+            s.export_device(keys.data_ptr(), cnt.data_ptr())    # synchronises the engine's stream
+        return keys, cnt
+
     def flush(self):
         self.eng.sync()                       # export copies ran on the engine's stream
 
@@ -212,6 +223,60 @@ def across_groups_distributed(ops, group_sets: Sequence, k: int, cs: int, hist_l
     return out
 
 
+def across_set_exchange(ops, aset, k: int, cs: int, hist_len: int, group=None) -> np.ndarray:
+    """Global step_8 histogram from every rank's LOCAL across-group set (the union of its own group
+    sets, counter = number of its groups holding the k-mer — what the fused kh_exp1_run emits).
+    The set is sorted by mixed key, so its slices by owner rank are contiguous and already in
+    destination order: the set's own storage is the send buffer.  Collectives: one small
+    all_to_all of the slice sizes, one of the keys, one of the counters, one all_reduce of the
+    histogram.  The receiver sums the counters of equal keys (saturating at cs) in one pass.
+    Collective: every rank must call it."""
+    world = dist.get_world_size(group)
+    dev = ops.device
+    trace = _Trace("across_set")
+    cdev = getattr(ops, "comm_device", dev)
+    to_comm = getattr(ops, "to_comm", lambda t: t)
+    from_comm = getattr(ops, "from_comm", lambda t: t)
+    w = ops.words(k)
+    bounds = np.asarray(ops.partition_bounds(aset, world), dtype=np.int64)
+    send_n = bounds[1:] - bounds[:-1]
+    sl = torch.from_numpy(send_n.copy()).to(cdev)
+    rl = torch.empty(world, dtype=torch.int64, device=cdev)
+    dist.all_to_all_single(rl, sl, group=group)
+    recv_n = rl.cpu().numpy()
+    trace("bounds+sizes")
+    skeys, scnt = ops.export_all(aset)
+    trace("export")
+    rkeys = torch.empty(int(recv_n.sum()) * w, dtype=torch.int64, device=cdev)
+    rcnt = torch.empty(int(recv_n.sum()), dtype=torch.int32, device=cdev)
+    dist.all_to_all_single(rkeys, to_comm(skeys), output_split_sizes=[int(n) * w for n in recv_n],
+                           input_split_sizes=[int(n) * w for n in send_n], group=group)
+    dist.all_to_all_single(rcnt, to_comm(scnt), output_split_sizes=[int(n) for n in recv_n],
+                           input_split_sizes=[int(n) for n in send_n], group=group)
+    rkeys, rcnt = from_comm(rkeys), from_comm(rcnt)
+    ops.before_wrap()
+    trace("all_to_all")
+    slices, off = [], 0
+    for i in range(world):
+        n = int(recv_n[i])
+        if n:
+            slices.append(ops.wrap(k, n, rkeys[off * w:(off + n) * w], rcnt[off:off + n]))
+        off += n
+    if slices:
+        _, hist = ops.union_hist(slices, cs, hist_len)
+        hist = np.asarray(hist)
+    else:
+        hist = np.zeros(hist_len, dtype=np.uint64)
+    del slices
+    trace("union")
+    ht = torch.from_numpy(hist.astype(np.int64)).to(cdev)
+    dist.all_reduce(ht, op=dist.ReduceOp.SUM, group=group)
+    out = ht.cpu().numpy().astype(np.uint64)
+    trace("all_reduce")
+    trace.report()
+    return out
+
+
 TABLE_MAX_K = 16      # 4^16 one-byte cells = 4 GiB of the 288 GB
 
 
@@ -274,9 +339,16 @@ def exp1_step(eng, seqs, group_of: Sequence[int], k: int, cs: int = 5000, hist_l
     """One benchmark step on N GPUs: steps 1-6 locally, steps 7-8 through the exchange.
     Returns the same dict as Engine.exp1_run (across_hist is the GLOBAL histogram)."""
     device = torch.device("cuda", eng.device)
-    res = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len, want_sets=True, across=False)
     ops = EngineOps(eng, device, stage_on_host=dist.get_backend(group) == "gloo")
-    gsets = [s.set_counts(1) for s in res["group_sets"]]
-    res["across_hist"] = across_groups_auto(ops, gsets, k, cs, hist_len, group)
-    del res["group_sets"]
+    if k <= TABLE_MAX_K:      # small k: the bitmap / table form may win, it needs the group sets
+        res = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len, want_sets=True, across=False)
+        gsets = [s.set_counts(1) for s in res["group_sets"]]
+        res["across_hist"] = across_groups_auto(ops, gsets, k, cs, hist_len, group)
+        del res["group_sets"]
+        return res
+    # the fused local step, emitting only this rank's across-group set (counter = local groups)
+    res = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len, across=False, want_across_set=True)
+    aset = res.pop("across_set")
+    res["across_hist"] = across_set_exchange(ops, aset, k, cs, hist_len, group)
+    aset.free()
     return res

@@ -336,16 +336,20 @@ class Engine:
         _check(self._lib.kh_union_histogram(self._ctx, arr, len(sets), cs, _u64p(hist), hist_len))
         return hist
 
-    def simple(self, a: KmerSet, b: KmerSet, op: int, mode: str = "min", cs: int = KMC_DEFAULT_CS) -> KmerSet:
+    def simple(self, a: KmerSet, b: KmerSet, op: int, mode: str = "min", cs: Optional[int] = None) -> KmerSet:
+        """cs None = no -cs on the command line: the larger counter range of the two operands (what
+        bin/kmc_tools does; parity unpinned, see kh_cli.cpp do_simple)."""
+        if cs is None:
+            cs = max(a.counter_max(), b.counter_max())
         out = C.c_void_p()
         _check(self._lib.kh_simple(self._ctx, a._h, b._h, op, MODE[mode], cs, C.byref(out)))
         return KmerSet(self, out.value)
 
-    def intersect(self, a, b, mode="min", cs=KMC_DEFAULT_CS):
+    def intersect(self, a, b, mode="min", cs=None):
         """`kmc_tools simple A B intersect OUT [-oc<mode>]` (exp_type_2.smk:363-365)."""
         return self.simple(a, b, INTERSECT, mode, cs)
 
-    def kmers_subtract(self, a, b, cs=KMC_DEFAULT_CS):
+    def kmers_subtract(self, a, b, cs=None):
         """`kmc_tools simple A B kmers_subtract OUT` (exp_type_2.smk:377-379)."""
         return self.simple(a, b, KMERS_SUBTRACT, "left", cs)
 

@@ -36,6 +36,8 @@ typedef struct {
     uint32_t* counts;
 } kho_db;
 
+static int g_inner_threads = 1;   /* threads inside one sort (kho_exp1 sets it; 1 = the serial passes) */
+
 #define KEY_T uint64_t
 #define SFX 64
 #include "kh_oracle_impl.inc"
@@ -76,17 +78,28 @@ int kho_exp1(int nseq, const uint8_t* const* seqs, const uint64_t* lens, const i
     kho_db* g = (kho_db*)calloc(nseq, sizeof *g);
     kho_db* u = (kho_db*)calloc(ngroups, sizeof *u);
     int used = 1, err = 0;
+    int outer = 1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
     used = omp_get_max_threads();
-    if (used > nseq) used = nseq;
+    /* more threads than genomes: the surplus works INSIDE the sorts (parallel radix passes) */
+    outer = used > nseq ? nseq : used;
+    g_inner_threads = used / outer > 1 ? used / outer : 1;
+    omp_set_max_active_levels(2);
 #endif
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(outer)
     for (int i = 0; i < nseq; ++i) {
         if (kho_count(seqs[i], lens[i], k, 1, 0xffffffffu, 255, &g[i]) != 0) err = 1;
         else { kho_set_counts(&g[i], 1); if (distinct_per_seq) distinct_per_seq[i] = g[i].n; }
     }
-#pragma omp parallel for schedule(dynamic, 1)
+#ifdef _OPENMP
+    {   /* group unions: fewer, larger sorts */
+        const int og = used > ngroups ? ngroups : used;
+        g_inner_threads = used / og > 1 ? used / og : 1;
+        outer = og;
+    }
+#endif
+#pragma omp parallel for schedule(dynamic, 1) num_threads(outer)
     for (int grp = 0; grp < ngroups; ++grp) {
         const kho_db** in = (const kho_db**)malloc(nseq * sizeof *in);
         int m = 0;
@@ -98,6 +111,7 @@ int kho_exp1(int nseq, const uint8_t* const* seqs, const uint64_t* lens, const i
         }
         free(in);
     }
+    g_inner_threads = used;   /* the across-group union is one sort: all threads inside it */
     if (!err) {
         const kho_db** in = (const kho_db**)malloc(ngroups * sizeof *in);
         for (int grp = 0; grp < ngroups; ++grp) in[grp] = &u[grp];
@@ -110,5 +124,6 @@ int kho_exp1(int nseq, const uint8_t* const* seqs, const uint64_t* lens, const i
     for (int grp = 0; grp < ngroups; ++grp) kho_free(&u[grp]);
     free(g);
     free(u);
+    g_inner_threads = 1;
     return err ? -1 : used;
 }

@@ -56,6 +56,10 @@ class OracleOps:
         assert (self.slot(s[0][lo:hi], self.world) == self.rank).all()
         return s[0][lo:hi], (s[1][lo:hi] if s[1] is not None else None)
 
+    def export_all(self, s):
+        c = s[1] if s[1] is not None else np.ones(s[0].size, dtype=np.uint32)
+        return torch.from_numpy(s[0].view(np.int64).copy()), torch.from_numpy(c.view(np.int32).copy())
+
     def flush(self):
         pass
 
@@ -147,6 +151,49 @@ def test_across_groups_exchange_matches_single_process(layout, with_counts):
     for _, h in got:
         assert h == want
     assert sum(want[2:]) > 0          # the shared block makes some k-mers multi-group
+
+
+def aset_worker(rank, world, port, groups_per_rank, q):
+    from khoice_amd import dist as kdist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        ops = OracleOps(K, rank, world)
+        first = 1 + sum(groups_per_rank[:rank])
+        # this rank's across-group set: union of its group sets, counter = local groups holding the key
+        local = O.union_sum([group_db(first + g) for g in range(groups_per_rank[rank])], 5000) \
+            if groups_per_rank[rank] else {}
+        from khoice_amd import engine as E
+        keys = np.array(sorted(local), dtype=np.uint64)
+        mixed = np.array([int(E.mix_host(K, np.array([v], dtype=np.uint64))[0]) for v in keys], dtype=np.uint64)
+        order = np.argsort(mixed)
+        aset = (mixed[order], np.array([local[int(v)] for v in keys], dtype=np.uint32)[order])
+        hist = kdist.across_set_exchange(ops, aset, K, 5000, 64)
+        q.put((rank, hist.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout", [[3, 3], [2, 0, 3]])
+def test_across_set_exchange_matches_single_process(layout):
+    """The exchange the benchmark takes at N > 1: every rank ships slices of its local across-group
+    set (keys + counters); the owners sum the counters."""
+    from khoice_amd import build as kbuild
+    kbuild.build_library()
+    world = len(layout)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=aset_worker, args=(r, world, port, layout, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = O.histogram(O.union_sum([group_db(1 + g) for g in range(sum(layout))], 5000), 63)
+    for _, h in got:
+        assert h == want
+    assert sum(want[2:]) > 0
 
 
 def table_worker(rank, world, port, groups_per_rank, k, q):

@@ -16,3 +16,19 @@ def test_two_ranks_share_one_gpu():
                         os.path.join(HERE, "dist_rehearsal.py")],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "REHEARSAL_OK" in r.stdout, r.stdout[-3000:]
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what the driver runs): the parent
+    starts the ranks itself, before touching HIP, and relays rank 0's line."""
+    import json
+    env = dict(os.environ, KHOICE_SHARE_GPU="1", KHOICE_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--species", "3", "--genomes", "2", "--length", "400000", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0

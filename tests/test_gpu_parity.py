@@ -511,3 +511,21 @@ def test_union_histogram_chains_equal_union_sum(eng, k):
     assert (eng.union_histogram(many, 5000, 200) == want2).all()
     empty = eng.build(b"ACG", k).set_counts(1)
     assert int(eng.union_histogram([empty, empty], 5000, 8).sum()) == 0
+
+
+def test_corrupt_slot_bounds_fail_closed(eng, monkeypatch):
+    """A slot bound outside its operand (planted through the KHOICE_DEBUG_CORRUPT_BOUNDS hook) must
+    end in an error from the library — the gather is never run through it — for both forms of the
+    operand description (up to 64 operands per wave lane, more through LDS descriptors)."""
+    from khoice_amd.engine import KhoiceError
+    rng = random.Random(99)
+    sets = [eng.build(random_dna(rng, 30_000).encode(), 31).set_counts(1) for _ in range(3)]
+    want, _ = eng.union_sum(sets, 255, hist_len=8)
+    monkeypatch.setenv("KHOICE_DEBUG_CORRUPT_BOUNDS", "1")
+    for operands in (sets, sets * 22):                      # 3 operands / 66 operands
+        with pytest.raises(KhoiceError) as ei:
+            eng.union_sum(operands, 5000)
+        assert "not sorted" in str(ei.value)
+    monkeypatch.delenv("KHOICE_DEBUG_CORRUPT_BOUNDS")
+    again, _ = eng.union_sum(sets, 255, hist_len=8)          # the context is still usable
+    assert len(again) == len(want)

@@ -122,10 +122,12 @@ def expected_type2_outputs(root, k_values, n, exp_dir):
         for num in range(n):
             across = O.union_sum([group_sets[i] for i in range(n) if i != num], 5000)
             for scope, other in (("within", unions[num]), ("across", across)):
-                for op, db in (("intersect", O.intersect(pivots[num], other, "sum")),
+                # `simple` without -cs: the output takes the larger counter range of its operands, here
+                # the -cs5000 unions (two counter bytes: 65535 histogram lines); parity unpinned
+                for op, db in (("intersect", O.intersect(pivots[num], other, "sum", 5000)),
                                ("subtract", O.kmers_subtract(pivots[num], other))):
                     rel = f"{scope}_dataset_results_type_2/k_{k}/dataset_{num + 1}/{op}/dataset_{num + 1}_pivot_{op}_group.hist.txt"
-                    files[rel] = O.histogram_text(db, 255)
+                    files[rel] = O.histogram_text(db, 65535)
     for rel, text in files.items():
         os.makedirs(os.path.dirname(os.path.join(exp_dir, rel)), exist_ok=True)
         open(os.path.join(exp_dir, rel), "w").write(text)

@@ -14,7 +14,7 @@ out, tag = sys.argv[1], sys.argv[2]
 CLASS = {"k_extract<1, false>": "extract_hist", "k_extract<2, false>": "extract_hist",
          "k_extract_staged": "extract_scatter", "k_extract<1, true>": "extract_scatter",
          "k_extract<2, true>": "extract_scatter", "k_bucket_sort_rle": "bucket_sort_rle",
-         "k_setop": "setop", "k_range_bounds": "range_bounds"}
+         "k_setop": "setop", "k_range_bounds": "range_bounds", "k_union_tagged": "union_tagged"}
 
 
 def cls(name):
@@ -48,5 +48,13 @@ for c, t in traffic.items():
               "fetch_bytes_per_launch": int(2 * t["fetch_kb"] * 1024 / n),
               "write_bytes_per_launch": int(t["write_kb"] * 1024 / n)}
     res[c]["bytes_per_launch"] = res[c]["fetch_bytes_per_launch"] + res[c]["write_bytes_per_launch"]
+# the sources these counters were collected on (bench.py refuses the file for any other sources)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402
+res["_source_sha"] = source_hash()
+steps_profiled = 3          # collect_profiles.sh: --steps 2 --warmup 1 in the PMC passes
+res["_bytes_per_step"] = int(sum(v["bytes_per_launch"] * v["launches_profiled"] for k, v in res.items()
+                                 if isinstance(v, dict)) / steps_profiled)
 json.dump(res, open(f"gpurun_out/{tag}_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
