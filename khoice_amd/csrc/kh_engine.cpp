@@ -1624,22 +1624,76 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
             return kh_fail(KH_E_ARG, "group_of[%d]=%d outside [0,%d)", i, group_of[i], ngroups);
     KHCHK(check_k(k));
     if (cs < 1) return kh_fail(KH_E_ARG, "cs must be >= 1");
-    // No per-group database wanted and everything fits one wave: the fused form (one build in grid
-    // mode + one tagged union); anything it cannot take falls through to the general path below.
+    // No per-group database wanted: the fused form (one build in grid mode + one tagged union per
+    // BATCH of whole groups; a batch holds at most 64 genomes — the width of the genome mask — and
+    // fits the memory budget).  One batch: its histograms are the answer.  Several: each batch also
+    // emits its across-group set (counter = groups of the batch holding the k-mer) and one
+    // counter-summing union of those sets gives step 7/8.  Anything the fused form cannot take
+    // (a group of more than 64 genomes, a slot overflow) falls through to the general path below.
     if (!group_sets && !getenv("KHOICE_NO_FUSED")) {
-        u64 all_bases = 0;
-        for (int i = 0; i < nseq; ++i) all_bases += lens[i];
         u64 fbudget = 4ull << 30;
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipSetDevice(c->dev));
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             fbudget = std::max<u64>(1u << 20, (free_b + c->pool.cached_bytes) / (k <= 32 ? 64 : 96));
         if (const char* e = getenv("KHOICE_WAVE_BASES")) fbudget = std::max<u64>(1, strtoull(e, nullptr, 10));
-        if (all_bases <= fbudget) {
+        std::vector<u64> gbases(ngroups, 0);
+        std::vector<int> gcount(ngroups, 0);
+        for (int i = 0; i < nseq; ++i) { gbases[group_of[i]] += lens[i]; gcount[group_of[i]]++; }
+        std::vector<int> batch_end;      // group index one past each batch
+        bool applicable = true;
+        {
+            u64 acc_b = 0;
+            int acc_n = 0, acc_g = 0, acc_bins = 0;
+            for (int g = 0; g < ngroups && applicable; ++g) {
+                if (gcount[g] > KH_TAG_MAX_OPS || gbases[g] > fbudget || gcount[g] == 0) { applicable = false; break; }
+                const bool fits = acc_n + gcount[g] <= KH_TAG_MAX_OPS && acc_g + 1 <= KH_TAG_MAX_OPS &&
+                                  acc_bins + gcount[g] + 1 + (acc_g + 2) <= KH_TAG_MAX_BINS && acc_b + gbases[g] <= fbudget;
+                if (!fits) { batch_end.push_back(g); acc_b = 0; acc_n = acc_g = acc_bins = 0; }
+                acc_b += gbases[g]; acc_n += gcount[g]; acc_g += 1; acc_bins += gcount[g] + 1;
+            }
+            batch_end.push_back(ngroups);
+        }
+        if (applicable && batch_end.size() == 1) {
             bool done = false;
             KHCHK(exp1_fused(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, within_hist, across_hist,
                              hist_len, distinct_per_seq, across_set, &done));
             if (done) return KH_OK;
+        } else if (applicable) {
+            const bool want_across = across_hist || across_set;
+            std::vector<kh_set*> asets;
+            auto drop = [&]() { for (auto* s : asets) kh_set_free(s); asets.clear(); };
+            bool ok = true;
+            int g0 = 0;
+            for (size_t b = 0; b < batch_end.size() && ok; ++b) {
+                const int g1 = batch_end[b];
+                std::vector<int> idx;
+                for (int i = 0; i < nseq; ++i)
+                    if (group_of[i] >= g0 && group_of[i] < g1) idx.push_back(i);
+                std::vector<const uint8_t*> bs(idx.size());
+                std::vector<uint64_t> bl(idx.size()), bd(idx.size(), 0);
+                std::vector<int> bg(idx.size());
+                for (size_t j = 0; j < idx.size(); ++j) { bs[j] = seqs[idx[j]]; bl[j] = lens[idx[j]]; bg[j] = group_of[idx[j]] - g0; }
+                kh_set* aset = nullptr;
+                bool done = false;
+                int r = exp1_fused(c, (int)idx.size(), bs.data(), bl.data(), on_device, bg.data(), g1 - g0, k, cs,
+                                   within_hist ? within_hist + (size_t)g0 * hist_len : nullptr, nullptr, hist_len,
+                                   bd.data(), want_across ? &aset : nullptr, &done);
+                if (r != KH_OK) { drop(); return r; }
+                if (!done) { ok = false; break; }
+                if (aset) asets.push_back(aset);
+                if (distinct_per_seq)
+                    for (size_t j = 0; j < idx.size(); ++j) distinct_per_seq[idx[j]] = bd[j];
+                g0 = g1;
+            }
+            if (ok) {
+                int r = KH_OK;
+                if (across_set) r = kh_union_sum(c, asets.data(), (int)asets.size(), cs, across_set, across_hist, hist_len);
+                else if (across_hist) r = kh_union_histogram(c, asets.data(), (int)asets.size(), cs, across_hist, hist_len);
+                drop();
+                return r;
+            }
+            drop();
         }
     }
     std::vector<kh_set*> gsets(nseq, nullptr), unions(ngroups, nullptr), usets(ngroups, nullptr);

@@ -90,3 +90,91 @@ def test_cfg5_saturation_5001_clone_group(eng):
     # without saturation the shared k-mers would read 5001
     union2, hist2 = eng.union_sum(sets, 100000, hist_len=5002)
     assert int(hist2[5001]) == both and int(hist2[5000]) == len(da) - both
+
+
+def check_reference_invariants(eng, seqs, group_of, got, k):
+    """The reference's own inline checks, as properties of a full-size run:
+    exp_type_6.smk:222-236  the largest non-empty bin of a union histogram is <= the number of inputs;
+    exp_type_3.smk:298      the histogram of a plain set (set_counts 1) lies entirely in bin 1;
+    exp_type_3.smk:314 / exp_type_2.smk:183-184  an `intersect -ocsum` of two plain sets has bin 1 empty;
+    exp_type_2.smk:202-203  a `kmers_subtract` result of a plain set lies entirely in bin 1;
+    exp_type_1.smk:141-142  the four percentage metrics of the summariser add up to 1 +- 0.05."""
+    from khoice_amd import summarize as S
+    ngroups = max(group_of) + 1
+    for g in range(ngroups):
+        members = sum(1 for x in group_of if x == g)
+        nz = np.nonzero(got["within_hist"][g])[0]
+        assert nz.size and nz.max() <= members and nz.min() >= 1
+        row = S.summarize_histogram_type1([int(x) for x in got["within_hist"][g][1:256]], members, False, k)
+        assert abs(sum(row[:4]) - 1.0) <= 0.05
+    nz = np.nonzero(got["across_hist"])[0]
+    assert nz.size and nz.max() <= ngroups and nz.min() >= 1
+    # pivot = the first genome, group = the rest of its species (the experiment-type-2/3 shape)
+    first = [i for i, g in enumerate(group_of) if g == 0]
+    sets = eng.build_batch([seqs[i] for i in first], k, with_counts=False)
+    pivot, rest = sets[0], eng.union_sum(sets[1:], 5000).set_counts(1)
+    assert int(pivot.histogram(256)[1]) == len(pivot) and int(pivot.histogram(256)[2:].sum()) == 0
+    inter = eng.intersect(pivot, rest, "sum")
+    hi = inter.histogram(256)
+    assert int(hi[1]) == 0 and int(hi[2]) == len(inter)
+    sub = eng.kmers_subtract(pivot, rest)
+    hs = sub.histogram(256)
+    assert int(hs[1]) == len(sub) and int(hs[2:].sum()) == 0
+    assert len(inter) + len(sub) == len(pivot)
+    return pivot
+
+
+def test_cfg2_full_size_5x5x5mbp(eng):
+    """BASELINE configs[1] exactly: 5 species x 5 genomes x 5 Mbp, k = 31 — per-genome distinct
+    counts, all five step_4 histograms and the step_8 histogram against the C restatement."""
+    from khoice_amd import synth
+    from oracle import c_oracle as CO
+    items = synth.species_set(5, 5, 5_000_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    got = eng.exp1_run(seqs, group_of, 31, cs=5000, hist_len=5001)
+    want = CO.exp1(seqs, group_of, 31, cs=5000, hist_len=5001)
+    assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+    assert (got["within_hist"] == want["within_hist"]).all()
+    assert (got["across_hist"] == want["across_hist"]).all()
+    pivot = check_reference_invariants(eng, seqs, group_of, got, 31)
+    # src/merge_lists.py:166-167 looks every canonical k-mer of a pivot read up in the pivot's dump
+    # (a KeyError if one is missing): every window of a read cut from the pivot genome must be there
+    from oracle import kmer_oracle as O
+    keys, _ = pivot.download_sorted()
+    have = set(int(x) for x in keys[:, 0])
+    text = seqs[0].decode()
+    rng = np.random.default_rng(7)
+    checked = 0
+    for _ in range(200):
+        at = int(rng.integers(0, len(text) - 150))
+        read = text[at:at + 150]
+        if any(ch not in "ACGT" for ch in read):
+            continue
+        for w in O.windows(read, 31):
+            assert O.encode(O.canonical_str(w)) in have
+            checked += 1
+    assert checked > 10_000
+
+
+@pytest.mark.parametrize("k", [31, 41])
+def test_cfg3_full_size_10x10x5mbp(eng, k):
+    """BASELINE configs[2] at its stated size: 10 species x 10 genomes x 5 Mbp (100 genomes: the
+    fused path runs it as batches of whole groups) — step_4 and step_8 histograms and the
+    per-genome distinct counts against the C restatement, plus the reference's invariants."""
+    from khoice_amd import synth
+    from oracle import c_oracle as CO
+    items = synth.species_set(10, 10, 5_000_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    eng.profile(True)
+    before = eng.stats()["kernels"]["union_tagged"]["launches"]
+    got = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=5001)
+    assert eng.stats()["kernels"]["union_tagged"]["launches"] - before == 2      # two batches of groups
+    eng.profile(False)
+    want = CO.exp1(seqs, group_of, k, cs=5000, hist_len=5001)
+    assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+    assert (got["within_hist"] == want["within_hist"]).all()
+    assert (got["across_hist"] == want["across_hist"]).all()
+    check_reference_invariants(eng, seqs, group_of, got, k)
+    eng.trim()
