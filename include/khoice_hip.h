@@ -87,6 +87,18 @@ int kh_build_fasta(kh_ctx *ctx, const char *path, int k, uint32_t ci, uint32_t c
 int kh_read_fasta(const char *path, uint8_t **seq, uint64_t *len);
 void kh_free_host(void *p);
 
+/* Batched ingest (the inputs the dataset_N/GENOME.fna.gz files of exp_type_1.smk:44-47,158):
+ * nfiles (gz) multi-FASTA files -> cleaned sequence text RESIDENT IN DEVICE MEMORY, exactly the
+ * bytes kh_read_fasta returns.  nthreads host threads inflate into pinned buffers (0 = one per
+ * core, at most 32); files are shipped and cleaned on the device as they complete, overlapping
+ * the inflation of the others.  The texts are read in place by kh_build_batch / kh_exp1_run
+ * (on_device = 1): kh_seqs_get gives pointer and length of text i; kh_seqs_free releases them. */
+typedef struct kh_seqs kh_seqs;
+int kh_ingest_fasta(kh_ctx *ctx, int nfiles, const char *const *paths, int nthreads, kh_seqs **out);
+int kh_seqs_count(const kh_seqs *seqs);
+int kh_seqs_get(const kh_seqs *seqs, int i, const uint8_t **dev_ptr, uint64_t *len);
+void kh_seqs_free(kh_seqs *seqs);
+
 /* ---------------------------------------------------------------- K2: set_counts
  * `kmc_tools transform IN set_counts {v} OUT`     exp_type_1.smk:173,241
  * O(1): the result shares IN's key storage and carries a uniform counter. */
@@ -143,6 +155,10 @@ int kh_confusion_row(kh_ctx *ctx, const kh_set *pivot, const kh_set *const *sets
 
 /* text form consumed at exp_type_1.smk:210-212: lines "c<TAB>n", c = 1..cmax */
 int kh_histogram_file(kh_ctx *ctx, const kh_set *set, uint32_t cmax, const char *path);
+
+/* the same text from a histogram array in host memory (what kh_exp1_run returns): counters past
+ * hist_len read 0 */
+int kh_write_histogram_text(const char *path, const uint64_t *hist, uint32_t hist_len, uint32_t cmax);
 
 /* ---------------------------------------------------------------- K7: sorted dump
  * `kmc_tools transform IN dump -s OUT.txt`        exp_type_4.smk:255-257,268-270

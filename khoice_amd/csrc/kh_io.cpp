@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -85,6 +86,229 @@ extern "C" int kh_build_fasta(kh_ctx* c, const char* path, int k, uint32_t ci, u
     r = kh_build_batch(c, 1, seqs, &len, 0, k, ci, cx, cs, 1, out);
     free(seq);
     return r;
+}
+
+// ------------------------------------------------------------------------------ batched ingest
+// kh_ingest_fasta: many (gz) multi-FASTA files -> cleaned sequence text resident in HBM, the form
+// kh_build_batch / kh_exp1_run read in place (inputs of exp_type_1.smk:44-47,158).
+//   worker threads   inflate one file each straight into a pinned buffer (sized from the gz
+//                    trailer) and sweep its line starts with memchr: one "the line running into
+//                    this 4 KB tile is a header line" flag per tile — the only sequential part of
+//                    FASTA cleaning;
+//   calling thread   as files complete (any order): one H2D copy of raw bytes + flags, then the
+//                    three small kernels of kh_ingest.hip (count, scan, write) on the context's
+//                    stream, while the other files are still being inflated.
+// The result is byte-identical to kh_read_fasta's text (tests/test_gpu_ingest.py).
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+size_t kh_fasta_clean_workspace(u64 raw_len);
+u32 kh_fasta_tile_bytes();
+void kh_launch_fasta_clean(const u8* raw, u64 n, const u8* entry_hdr, u8* out, void* ws,
+                           unsigned long long* out_len, hipStream_t st);
+
+struct kh_seqs {
+    std::vector<DevBuf*> bufs;
+    std::vector<uint64_t> lens;
+};
+
+namespace {
+struct IngestFile {
+    std::string path;
+    uint8_t* host = nullptr;      // pinned: [raw bytes][pad to 16][entry flags]
+    size_t cap = 0;
+    uint64_t raw_len = 0, flags_off = 0, ntiles = 0;
+    std::string error;
+};
+
+// expected size of the inflated data: the ISIZE trailer of a single-member gzip file, the file
+// size for plain text; 0 = unknown (the buffer then grows as needed)
+uint64_t inflated_size_hint(const char* path, bool* is_gz) {
+    *is_gz = false;
+    FILE* f = fopen(path, "rb");
+    if (!f) return 0;
+    unsigned char magic[2] = {0, 0};
+    const size_t got = fread(magic, 1, 2, f);
+    struct stat sb;
+    uint64_t hint = 0;
+    if (fstat(fileno(f), &sb) == 0) {
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            *is_gz = true;
+            unsigned char t[4];
+            if (sb.st_size >= 18 && fseek(f, -4, SEEK_END) == 0 && fread(t, 1, 4, f) == 4) {
+                hint = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+                if (hint < (uint64_t)sb.st_size) hint = 0;   // multi-member or > 4 GiB: the trailer is no guide
+            }
+        } else {
+            hint = (uint64_t)sb.st_size;
+        }
+    }
+    fclose(f);
+    return hint;
+}
+
+// inflate into f.host (grown through `grow` when the hint was short), then the per-tile flags
+void ingest_read(IngestFile& f, const std::function<bool(IngestFile&, size_t)>& grow) {
+    gzFile g = gzopen(f.path.c_str(), "rb");
+    if (!g) { f.error = "cannot open " + f.path; return; }
+    gzbuffer(g, 1 << 20);
+    const uint32_t tile = kh_fasta_tile_bytes();
+    uint64_t n = 0;
+    for (;;) {
+        // room for the next chunk, the padding and the flags that follow the data
+        const size_t need = (size_t)n + (4u << 20) + 64 + (size_t)((n + (4u << 20)) / tile + 2);
+        if (need > f.cap && !grow(f, need + need / 4)) { f.error = "out of pinned host memory"; gzclose(g); return; }
+        const int got = gzread(g, f.host + n, 4u << 20);
+        if (got < 0) {
+            int e;
+            f.error = std::string("read error in ") + f.path + ": " + gzerror(g, &e);
+            gzclose(g);
+            return;
+        }
+        if (got == 0) break;
+        n += (uint64_t)got;
+    }
+    gzclose(g);
+    f.raw_len = n;
+    f.flags_off = (n + 15) & ~15ull;
+    f.ntiles = (n + tile - 1) / tile;
+    memset(f.host + n, '\n', (size_t)(f.flags_off - n));
+    uint8_t* flags = f.host + f.flags_off;
+    memset(flags, 0, (size_t)f.ntiles + 1);
+    // line sweep: a tile boundary p with ls < p <= le lies inside the line [ls, le]
+    const uint8_t* raw = f.host;
+    uint64_t ls = 0;
+    while (ls < n) {
+        const void* nl = memchr(raw + ls, '\n', (size_t)(n - ls));
+        const uint64_t le = nl ? (uint64_t)(static_cast<const uint8_t*>(nl) - raw) : n - 1;
+        uint64_t q = ls;
+        while (q <= le && raw[q] == '\r') ++q;
+        const bool hdr = q <= le && raw[q] == '>';
+        if (hdr)
+            for (uint64_t t = ls / tile + 1; t * tile <= le && t < f.ntiles; ++t) flags[t] = 1;
+        ls = le + 1;
+    }
+}
+}  // namespace
+
+extern "C" int kh_ingest_fasta(kh_ctx* c, int nfiles, const char* const* paths, int nthreads, kh_seqs** out) {
+    if (!c || !paths || !out || nfiles <= 0) return kh_fail(KH_E_ARG, "kh_ingest_fasta: bad argument");
+    if (hipSetDevice(c->dev) != hipSuccess) return kh_fail(KH_E_HIP, "hipSetDevice failed");
+    if (nthreads <= 0) nthreads = (int)std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency()));
+    nthreads = std::min(nthreads, nfiles);
+    std::vector<IngestFile> files(nfiles);
+    std::mutex pin_mu;   // hipHostMalloc from worker threads (growth only) is serialised
+    auto grow = [&](IngestFile& f, size_t want) -> bool {
+        std::lock_guard<std::mutex> lk(pin_mu);
+        void* p = nullptr;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return false;
+        if (f.host) { memcpy(p, f.host, std::min(f.cap, want)); (void)hipHostFree(f.host); }
+        f.host = static_cast<uint8_t*>(p);
+        f.cap = want;
+        return true;
+    };
+    const uint32_t tile = kh_fasta_tile_bytes();
+    auto cleanup_host = [&]() { for (auto& f : files) if (f.host) { (void)hipHostFree(f.host); f.host = nullptr; } };
+    for (int i = 0; i < nfiles; ++i) {
+        if (!paths[i]) { cleanup_host(); return kh_fail(KH_E_ARG, "kh_ingest_fasta: path %d is NULL", i); }
+        files[i].path = paths[i];
+        bool gz;
+        const uint64_t hint = inflated_size_hint(paths[i], &gz);
+        if (hint) {   // exact-size pinned buffer up front (the workers then never allocate)
+            const size_t want = (size_t)hint + (4u << 20) + 64 + (size_t)((hint + (4u << 20)) / tile + 2) + 4096;
+            if (!grow(files[i], want)) { cleanup_host(); return kh_fail(KH_E_NOMEM, "pinned host allocation of %zu bytes failed", want); }
+        }
+    }
+    // workers: files in order; completion is signalled through `ready`
+    std::atomic<int> next{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> ready;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t)
+        pool.emplace_back([&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= nfiles) break;
+                ingest_read(files[i], grow);
+                { std::lock_guard<std::mutex> lk(mu); ready.push_back(i); }
+                cv.notify_one();
+            }
+        });
+    kh_seqs* res = new kh_seqs;
+    res->bufs.assign(nfiles, nullptr);
+    res->lens.assign(nfiles, 0);
+    int rc = KH_OK;
+    std::string err;
+    // device-side lengths, read back once at the end
+    DevBuf* d_len = c->buf_alloc(8 * (size_t)nfiles);
+    if (!d_len) { rc = KH_E_NOMEM; err = "device allocation failed"; }
+    int done = 0;
+    while (done < nfiles) {
+        int i;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&]() { return !ready.empty(); });
+            i = ready.back();
+            ready.pop_back();
+        }
+        ++done;
+        IngestFile& f = files[i];
+        if (rc != KH_OK) continue;
+        if (!f.error.empty()) { rc = KH_E_IO; err = f.error; continue; }
+        const size_t ship = (size_t)(f.flags_off + f.ntiles + 1);
+        DevBuf* d_raw = c->buf_alloc(ship + 16);
+        DevBuf* d_out = c->buf_alloc((size_t)f.raw_len + 256);      // 16-byte loads may run past the last base
+        DevBuf* d_ws = c->buf_alloc(kh_fasta_clean_workspace(f.raw_len));
+        if (!d_raw || !d_out || !d_ws) {
+            buf_unref(d_raw); buf_unref(d_out); buf_unref(d_ws);
+            rc = KH_E_NOMEM; err = "device allocation failed";
+            continue;
+        }
+        c->prof_begin(KC_COPY_IN);
+        hipError_t e = hipMemcpyAsync(d_raw->p, f.host, ship, hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) {
+            kh_launch_fasta_clean(static_cast<const u8*>(d_raw->p), f.raw_len, static_cast<const u8*>(d_raw->p) + f.flags_off,
+                                  static_cast<u8*>(d_out->p), d_ws->p,
+                                  reinterpret_cast<unsigned long long*>(d_len->p) + i, c->st);
+            e = hipGetLastError();
+        }
+        c->prof_end();
+        buf_unref(d_raw);      // stream-ordered pool: reusable by whatever is queued after the kernels
+        buf_unref(d_ws);
+        if (e != hipSuccess) { buf_unref(d_out); rc = KH_E_HIP; err = hipGetErrorString(e); continue; }
+        res->bufs[i] = d_out;
+    }
+    for (auto& th : pool) th.join();
+    if (rc == KH_OK) {
+        if (hipMemcpyAsync(res->lens.data(), d_len->p, 8 * (size_t)nfiles, hipMemcpyDeviceToHost, c->st) != hipSuccess ||
+            hipStreamSynchronize(c->st) != hipSuccess) { rc = KH_E_HIP; err = "read-back of the text lengths failed"; }
+    } else {
+        (void)hipStreamSynchronize(c->st);
+    }
+    buf_unref(d_len);
+    cleanup_host();
+    if (rc != KH_OK) {
+        for (auto* b : res->bufs) buf_unref(b);
+        delete res;
+        return kh_fail(rc, "kh_ingest_fasta: %s", err.c_str());
+    }
+    *out = res;
+    return KH_OK;
+}
+extern "C" int kh_seqs_count(const kh_seqs* s) { return s ? (int)s->bufs.size() : 0; }
+extern "C" int kh_seqs_get(const kh_seqs* s, int i, const uint8_t** dev_ptr, uint64_t* len) {
+    if (!s || i < 0 || i >= (int)s->bufs.size()) return kh_fail(KH_E_ARG, "kh_seqs_get: index out of range");
+    if (dev_ptr) *dev_ptr = static_cast<const uint8_t*>(s->bufs[i]->p);
+    if (len) *len = s->lens[i];
+    return KH_OK;
+}
+extern "C" void kh_seqs_free(kh_seqs* s) {
+    if (!s) return;
+    for (auto* b : s->bufs) buf_unref(b);
+    delete s;
 }
 
 // ------------------------------------------------------------------------------ container
@@ -272,3 +496,16 @@ extern "C" int kh_dump_sorted(kh_ctx* c, const kh_set* s, const char* path) {
     }
     return f.commit();
 }
+
+// text form of a histogram held in host memory (the fused kh_exp1_run hands back arrays, the
+// Snakemake rules declare step_4 / step_8 files): lines "c<TAB>n" for c = 1..cmax, counters past
+// the array read 0
+extern "C" int kh_write_histogram_text(const char* path, const uint64_t* hist, uint32_t hist_len, uint32_t cmax) {
+    if (!path || !hist || cmax < 1) return kh_fail(KH_E_ARG, "kh_write_histogram_text: bad argument");
+    AtomicFile f;
+    int r;
+    if ((r = f.open(path)) != KH_OK) return r;
+    for (uint32_t i = 1; i <= cmax; ++i) fprintf(f.f, "%u\t%llu\n", i, (unsigned long long)(i < hist_len ? hist[i] : 0));
+    return f.commit();
+}
+

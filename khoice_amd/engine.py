@@ -61,6 +61,11 @@ def load_library(path: Optional[str] = None):
                                      C.POINTER(vp)]),
         "kh_read_fasta": (C.c_int, [C.c_char_p, C.POINTER(vp), u64p]),
         "kh_free_host": (None, [vp]),
+        "kh_ingest_fasta": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(vp)]),
+        "kh_seqs_count": (C.c_int, [vp]),
+        "kh_seqs_get": (C.c_int, [vp, C.c_int, C.POINTER(vp), u64p]),
+        "kh_seqs_free": (None, [vp]),
+        "kh_write_histogram_text": (C.c_int, [C.c_char_p, u64p, C.c_uint32, C.c_uint32]),
         "kh_set_counts": (C.c_int, [vp, vp, C.c_uint32, C.POINTER(vp)]),
         "kh_union_sum": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_uint32, C.POINTER(vp), u64p, C.c_uint32]),
         "kh_union_histogram": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_uint32, u64p, C.c_uint32]),
@@ -105,7 +110,8 @@ def load_library(path: Optional[str] = None):
 ABI_SYMBOLS = [
     "kh_ctx_create", "kh_ctx_destroy", "kh_last_error", "kh_device_count", "kh_stats",
     "kh_profile_enable", "kh_stats_reset", "kh_sync", "kh_trim", "kh_build_batch", "kh_build_fasta",
-    "kh_read_fasta", "kh_free_host", "kh_set_counts", "kh_union_sum", "kh_union_histogram", "kh_simple", "kh_histogram",
+    "kh_read_fasta", "kh_free_host", "kh_ingest_fasta", "kh_seqs_count", "kh_seqs_get", "kh_seqs_free",
+    "kh_write_histogram_text", "kh_set_counts", "kh_union_sum", "kh_union_histogram", "kh_simple", "kh_histogram",
     "kh_histogram_file", "kh_membership", "kh_confusion_row",
     "kh_table_add_set", "kh_table_histogram", "kh_dump_sorted", "kh_set_free", "kh_set_info", "kh_set_counter_max",
     "kh_set_download",
@@ -223,6 +229,46 @@ class KmerSet:
         return b
 
 
+class DeviceTexts:
+    """Cleaned sequence texts resident in HBM (Engine.ingest_fasta); `seqs` is what build_batch /
+    exp1_run take: (device pointer, length) pairs.  Owned by the library until free()."""
+
+    def __init__(self, engine: "Engine", handle: int):
+        self._e, self._h = engine, C.c_void_p(handle)
+        n = engine._lib.kh_seqs_count(self._h)
+        self.seqs = []
+        for i in range(n):
+            p, ln = C.c_void_p(), C.c_uint64()
+            _check(engine._lib.kh_seqs_get(self._h, i, C.byref(p), C.byref(ln)))
+            self.seqs.append((p.value or 0, ln.value))
+
+    def total_bases(self) -> int:
+        return sum(n for _, n in self.seqs)
+
+    def download(self, i: int) -> bytes:
+        import ctypes
+        ptr, n = self.seqs[i]
+        buf = (ctypes.c_ubyte * max(n, 1))()
+        hip = ctypes.CDLL("libamdhip64.so")
+        if n:
+            rc = hip.hipMemcpy(buf, C.c_void_p(ptr), C.c_size_t(n), 2)      # hipMemcpyDeviceToHost
+            if rc != 0:
+                raise RuntimeError(f"hipMemcpy failed: {rc}")
+        return bytes(buf[:n])
+
+    def free(self):
+        if self._h:
+            self._e._lib.kh_seqs_free(self._h)
+            self._h = None
+            self.seqs = []
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Engine:
     """One HIP stream on one MI355X."""
 
@@ -306,6 +352,20 @@ class Engine:
         out = C.c_void_p()
         _check(self._lib.kh_build_fasta(self._ctx, path.encode(), k, ci, cx, cs, C.byref(out)))
         return KmerSet(self, out.value)
+
+    def ingest_fasta(self, paths: Sequence[str], threads: int = 0) -> DeviceTexts:
+        """(gz) FASTA files -> cleaned texts in HBM: parallel inflate into pinned memory on `threads`
+        host threads, FASTA cleaning on the device, file by file as they complete."""
+        n = len(paths)
+        arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+        out = C.c_void_p()
+        _check(self._lib.kh_ingest_fasta(self._ctx, n, arr, threads, C.byref(out)))
+        return DeviceTexts(self, out.value)
+
+    def write_histogram_text(self, path: str, hist: np.ndarray, cmax: int):
+        """`kmc_tools transform histogram` text (lines c<TAB>n, c = 1..cmax) from a histogram array."""
+        h = np.ascontiguousarray(hist, dtype=np.uint64)
+        _check(self._lib.kh_write_histogram_text(path.encode(), _u64p(h), h.size, cmax))
 
     def read_fasta(self, path: str) -> bytes:
         p, n = C.c_void_p(), C.c_uint64()

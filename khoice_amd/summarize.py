@@ -23,7 +23,7 @@ Implementation notes (why this is bit-identical although written differently):
 """
 from __future__ import annotations
 
-from typing import Callable, Iterable, List, Sequence
+from typing import Optional, Callable, Iterable, List, Sequence
 
 WITHIN_HEADER = ("group_num,k,percent_1_occ,percent_25_or_less,percent_25_to_75,"
                  "percent_75_or_more,unique_stat,unique_stat_norm,delta_frac,delta_frac_norm\n")
@@ -145,7 +145,7 @@ def _rows_to_csv(header: str, rows: Iterable[Sequence]) -> str:
 
 
 def within_groups_csv(hist_paths: Sequence[str], num_datasets: int,
-                      members_of: Callable[[str], int]) -> str:
+                      members_of: Callable[[str], int], hists: Optional[dict] = None) -> str:
     """CSV text of step_5/within_datasets_analysis.csv (exp_type_1.smk:199-231).
 
     `hist_paths` are `step_4/k_{k}/dataset_{num}/dataset_{num}_k{k}_hist.txt` in the
@@ -156,7 +156,9 @@ def within_groups_csv(hist_paths: Sequence[str], num_datasets: int,
         parts = path.split("/")
         k = parts[1][2:]
         num = parts[2].split("_")[1]
-        hist = read_histogram_file(path)
+        # `hists`: histograms the caller still holds in memory (the batched runner just wrote these
+        # files from them); same list the file would parse to
+        hist = hists[path] if hists and path in hists else read_histogram_file(path)
         rows.append([f"group_{num}", k]
                     + summarize_histogram_type1(hist, members_of(num), False, int(k)))
     for g in range(1, num_datasets + 1):
@@ -168,12 +170,12 @@ def within_groups_csv(hist_paths: Sequence[str], num_datasets: int,
     return _rows_to_csv(WITHIN_HEADER, rows)
 
 
-def across_groups_csv(hist_paths: Sequence[str], num_datasets: int) -> str:
+def across_groups_csv(hist_paths: Sequence[str], num_datasets: int, hists: Optional[dict] = None) -> str:
     """CSV text of step_9/across_datasets_analysis.csv (exp_type_1.smk:268-297)."""
     rows: List[list] = []
     for path in hist_paths:
         k = path.split("/")[1][2:]
-        hist = read_histogram_file(path)
+        hist = hists[path] if hists and path in hists else read_histogram_file(path)
         rows.append(["full_group", k]
                     + summarize_histogram_type1(hist, num_datasets, True, int(k)))
     peak = max(r[8] for r in rows)

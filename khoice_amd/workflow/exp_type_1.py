@@ -128,7 +128,7 @@ def across_group_union_histogram(sh, k):
        [out])
 
 
-def _csv_stage(work_root: str, k_values: Sequence[str], num_datasets: int) -> Dict[str, str]:
+def _csv_stage(work_root: str, k_values: Sequence[str], num_datasets: int, hists: Optional[dict] = None) -> Dict[str, str]:
     """Rules within_group_union_analysis, across_group_union_analysis and
     copy_final_results_type1 (exp_type_1.smk:193-231, 262-308)."""
     cwd = os.getcwd()
@@ -139,8 +139,8 @@ def _csv_stage(work_root: str, k_values: Sequence[str], num_datasets: int) -> Di
                          for k in k_values for num in range(1, num_datasets + 1)]
         across_inputs = [f"step_8/k_{k}/all_datasets_k{k}_hist.txt" for k in k_values]
         members = {str(n): len(genomes_of(".", n)) for n in range(1, num_datasets + 1)}
-        within = summarize.within_groups_csv(within_inputs, num_datasets, lambda n: members[str(n)])
-        across = summarize.across_groups_csv(across_inputs, num_datasets)
+        within = summarize.within_groups_csv(within_inputs, num_datasets, lambda n: members[str(n)], hists)
+        across = summarize.across_groups_csv(across_inputs, num_datasets, hists)
         os.makedirs("step_5", exist_ok=True)
         os.makedirs("step_9", exist_ok=True)
         os.makedirs("final_results_type1", exist_ok=True)
@@ -193,6 +193,41 @@ def run_batched(work_root: str, k_values: Sequence, num_datasets: int, device: i
             for g in genomes[num]:
                 group_of.append(num - 1)
                 names.append((num, g))
+        if not keep_databases:
+            # No intermediate database is wanted: the files are inflated on host threads into pinned
+            # memory and cleaned on the device as they complete (kh_ingest_fasta), every k is ONE
+            # fused kh_exp1_run on the resident texts, the step_4 / step_8 histogram files are written
+            # from the returned arrays and the CSV stage consumes those arrays (not a re-parse of six
+            # 65535-line files it has just written).
+            import numpy as np
+            paths = [os.path.join(work_root, f"data/dataset_{num}/{g}.fna.gz") for num, g in names]
+            texts = eng.ingest_fasta(paths)
+            t_ingest = time.perf_counter()
+            hists = {}
+            for k in k_values:
+                res = eng.exp1_run(texts.seqs, group_of, int(k), cs=5000, hist_len=5001)
+                pad = np.zeros(65536, dtype=np.uint64)
+                for num in range(1, num_datasets + 1):
+                    os.makedirs(os.path.join(work_root, f"step_4/k_{k}/dataset_{num}"), exist_ok=True)
+                    rel = f"step_4/k_{k}/dataset_{num}/dataset_{num}_k{k}_hist.txt"
+                    eng.write_histogram_text(os.path.join(work_root, rel), res["within_hist"][num - 1], 65535)
+                    pad[:5001] = res["within_hist"][num - 1]
+                    hists[rel] = pad[1:].tolist()
+                os.makedirs(os.path.join(work_root, f"step_8/k_{k}"), exist_ok=True)
+                rel = f"step_8/k_{k}/all_datasets_k{k}_hist.txt"
+                eng.write_histogram_text(os.path.join(work_root, rel), res["across_hist"], 65535)
+                pad[:5001] = res["across_hist"]
+                hists[rel] = pad[1:].tolist()
+            bases = texts.total_bases()
+            texts.free()
+            t_device = time.perf_counter()
+            eng.close()
+            out = _csv_stage(work_root, k_values, num_datasets, hists)
+            out["processes"] = 0
+            if timings is not None:
+                timings.update(ingest_s=t_ingest - t_start, device_and_files_s=t_device - t_ingest,
+                               csv_s=time.perf_counter() - t_device, bases=bases)
+            return out
         # host ingest (inflate + FASTA parsing) runs in the library without the GIL: one thread
         # per file up to the core count
         from concurrent.futures import ThreadPoolExecutor
