@@ -89,7 +89,7 @@ void kh_free_host(void *p);
 
 /* Batched ingest (the inputs the dataset_N/GENOME.fna.gz files of exp_type_1.smk:44-47,158):
  * nfiles (gz) multi-FASTA files -> cleaned sequence text RESIDENT IN DEVICE MEMORY, exactly the
- * bytes kh_read_fasta returns.  nthreads host threads inflate into pinned buffers (0 = one per
+ * bytes kh_read_fasta returns.  nthreads host threads inflate the files (0 = one per
  * core, at most 32); files are shipped and cleaned on the device as they complete, overlapping
  * the inflation of the others.  The texts are read in place by kh_build_batch / kh_exp1_run
  * (on_device = 1): kh_seqs_get gives pointer and length of text i; kh_seqs_free releases them. */

@@ -91,8 +91,7 @@ extern "C" int kh_build_fasta(kh_ctx* c, const char* path, int k, uint32_t ci, u
 // ------------------------------------------------------------------------------ batched ingest
 // kh_ingest_fasta: many (gz) multi-FASTA files -> cleaned sequence text resident in HBM, the form
 // kh_build_batch / kh_exp1_run read in place (inputs of exp_type_1.smk:44-47,158).
-//   worker threads   inflate one file each straight into a pinned buffer (sized from the gz
-//                    trailer) and sweep its line starts with memchr: one "the line running into
+//   worker threads   inflate one file each into a host buffer (sized from the gz trailer) and sweep its line starts with memchr: one "the line running into
 //                    this 4 KB tile is a header line" flag per tile — the only sequential part of
 //                    FASTA cleaning;
 //   calling thread   as files complete (any order): one H2D copy of raw bytes + flags, then the
@@ -117,7 +116,7 @@ struct kh_seqs {
 namespace {
 struct IngestFile {
     std::string path;
-    uint8_t* host = nullptr;      // pinned: [raw bytes][pad to 16][entry flags]
+    uint8_t* host = nullptr;      // [raw bytes][pad to 16][entry flags]
     size_t cap = 0;
     uint64_t raw_len = 0, flags_off = 0, ntiles = 0;
     std::string error;
@@ -159,7 +158,7 @@ void ingest_read(IngestFile& f, const std::function<bool(IngestFile&, size_t)>& 
     for (;;) {
         // room for the next chunk, the padding and the flags that follow the data
         const size_t need = (size_t)n + (4u << 20) + 64 + (size_t)((n + (4u << 20)) / tile + 2);
-        if (need > f.cap && !grow(f, need + need / 4)) { f.error = "out of pinned host memory"; gzclose(g); return; }
+        if (need > f.cap && !grow(f, need + need / 4)) { f.error = "out of host memory"; gzclose(g); return; }
         const int got = gzread(g, f.host + n, 4u << 20);
         if (got < 0) {
             int e;
@@ -199,26 +198,25 @@ extern "C" int kh_ingest_fasta(kh_ctx* c, int nfiles, const char* const* paths, 
     if (nthreads <= 0) nthreads = (int)std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency()));
     nthreads = std::min(nthreads, nfiles);
     std::vector<IngestFile> files(nfiles);
-    std::mutex pin_mu;   // hipHostMalloc from worker threads (growth only) is serialised
+    // Plain host buffers: page-locking 25 x 9 MB costs ~75 ms on this host — far more than what
+    // staged (pageable) copies lose over 125 MB — and a run ingests its files once.
     auto grow = [&](IngestFile& f, size_t want) -> bool {
-        std::lock_guard<std::mutex> lk(pin_mu);
-        void* p = nullptr;
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return false;
-        if (f.host) { memcpy(p, f.host, std::min(f.cap, want)); (void)hipHostFree(f.host); }
+        void* p = realloc(f.host, want);
+        if (!p) return false;
         f.host = static_cast<uint8_t*>(p);
         f.cap = want;
         return true;
     };
     const uint32_t tile = kh_fasta_tile_bytes();
-    auto cleanup_host = [&]() { for (auto& f : files) if (f.host) { (void)hipHostFree(f.host); f.host = nullptr; } };
+    auto cleanup_host = [&]() { for (auto& f : files) { free(f.host); f.host = nullptr; } };
     for (int i = 0; i < nfiles; ++i) {
         if (!paths[i]) { cleanup_host(); return kh_fail(KH_E_ARG, "kh_ingest_fasta: path %d is NULL", i); }
         files[i].path = paths[i];
         bool gz;
         const uint64_t hint = inflated_size_hint(paths[i], &gz);
-        if (hint) {   // exact-size pinned buffer up front (the workers then never allocate)
+        if (hint) {   // exact-size buffer up front (the workers then never reallocate)
             const size_t want = (size_t)hint + (4u << 20) + 64 + (size_t)((hint + (4u << 20)) / tile + 2) + 4096;
-            if (!grow(files[i], want)) { cleanup_host(); return kh_fail(KH_E_NOMEM, "pinned host allocation of %zu bytes failed", want); }
+            if (!grow(files[i], want)) { cleanup_host(); return kh_fail(KH_E_NOMEM, "host allocation of %zu bytes failed", want); }
         }
     }
     // workers: files in order; completion is signalled through `ready`
@@ -505,7 +503,22 @@ extern "C" int kh_write_histogram_text(const char* path, const uint64_t* hist, u
     AtomicFile f;
     int r;
     if ((r = f.open(path)) != KH_OK) return r;
-    for (uint32_t i = 1; i <= cmax; ++i) fprintf(f.f, "%u\t%llu\n", i, (unsigned long long)(i < hist_len ? hist[i] : 0));
+    // 65535 lines per file and six files per k: formatted by hand into one buffer (fprintf cost ~3 ms a file)
+    std::vector<char> buf;
+    buf.reserve((size_t)cmax * 14 + 64);
+    char tmp[24];
+    auto put = [&](unsigned long long v) {
+        int m = 0;
+        do { tmp[m++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (m) buf.push_back(tmp[--m]);
+    };
+    for (uint32_t i = 1; i <= cmax; ++i) {
+        put(i);
+        buf.push_back('\t');
+        put(i < hist_len ? hist[i] : 0ull);
+        buf.push_back('\n');
+    }
+    if ((r = write_all(f.f, buf.data(), buf.size(), path)) != KH_OK) return r;
     return f.commit();
 }
 

@@ -206,18 +206,20 @@ def run_batched(work_root: str, k_values: Sequence, num_datasets: int, device: i
             hists = {}
             for k in k_values:
                 res = eng.exp1_run(texts.seqs, group_of, int(k), cs=5000, hist_len=5001)
-                pad = np.zeros(65536, dtype=np.uint64)
+                def as_list(h):
+                    # what the histogram file parses to, cut behind its last non-zero line (never
+                    # shorter than KMC's 255 lines): the summariser only sums, trailing zeros add nothing
+                    nz = np.flatnonzero(h[1:])
+                    return h[1:max(256, int(nz[-1]) + 2 if nz.size else 0)].tolist()
                 for num in range(1, num_datasets + 1):
                     os.makedirs(os.path.join(work_root, f"step_4/k_{k}/dataset_{num}"), exist_ok=True)
                     rel = f"step_4/k_{k}/dataset_{num}/dataset_{num}_k{k}_hist.txt"
                     eng.write_histogram_text(os.path.join(work_root, rel), res["within_hist"][num - 1], 65535)
-                    pad[:5001] = res["within_hist"][num - 1]
-                    hists[rel] = pad[1:].tolist()
+                    hists[rel] = as_list(res["within_hist"][num - 1])
                 os.makedirs(os.path.join(work_root, f"step_8/k_{k}"), exist_ok=True)
                 rel = f"step_8/k_{k}/all_datasets_k{k}_hist.txt"
                 eng.write_histogram_text(os.path.join(work_root, rel), res["across_hist"], 65535)
-                pad[:5001] = res["across_hist"]
-                hists[rel] = pad[1:].tolist()
+                hists[rel] = as_list(res["across_hist"])
             bases = texts.total_bases()
             texts.free()
             t_device = time.perf_counter()
