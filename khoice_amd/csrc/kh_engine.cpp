@@ -411,6 +411,17 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     std::vector<KhTile> tiles;
     u64 seq_bytes = 0, total_pos = 0, thist_n = 0, bases = 0;
     u32 nb_total = 0, max_nb = 1;
+    // Positions per extraction workgroup (tile): 65536 amortises the cursor rows best, but a small
+    // batch (the per-call path: one 5 Mbp genome is 77 such tiles on 256 CUs) is cut finer so that
+    // passes A and B fill the chip — down to one staging round of pass B.
+    u32 tile_pos = KH_TILE;
+    {
+        u64 all_pos = 0;
+        for (int i = 0; i < nseq; ++i) all_pos += lens[i] >= (u64)k ? lens[i] - k + 1 : 0;
+        const u64 want_tiles = 4ull * (u64)std::max(1, c->cus);
+        while (tile_pos > 2 * KH_SUBTILE && (all_pos + tile_pos - 1) / tile_pos < want_tiles) tile_pos >>= 1;
+        if (const char* ev = getenv("KHOICE_TILE_POS")) tile_pos = std::max<u32>(2 * KH_SUBTILE, (u32)strtoul(ev, nullptr, 10) / (2 * KH_SUBTILE) * (2 * KH_SUBTILE));
+    }
     u64 grid_nb = 1;   // grid mode: one bucket grid for every sequence, sized by the longest
     if (grid)
         for (int i = 0; i < nseq; ++i)
@@ -430,7 +441,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
                            (unsigned long long)KH_MAX_BUCKETS_PER_SEG * mean);
         s.nbuckets = (u32)want_b;
         s.bucket_base = nb_total;
-        s.ntiles = (u32)((s.npos + KH_TILE - 1) / KH_TILE);
+        s.ntiles = (u32)((s.npos + tile_pos - 1) / tile_pos);
         s.tile_base = (u32)tiles.size();
         s.thist_base = thist_n;
         for (u32 t = 0; t < s.ntiles; ++t) tiles.push_back(KhTile{(u32)i, t});
@@ -541,7 +552,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     // ---- pass A, bucket plan, pass B
     c->prof_begin(KC_EXTRACT_HIST);
     kh_launch_extract(W, false, d_seq.as<u8>(), d_segs.as<KhSeg>(), d_tiles.as<KhTile>(), ntiles,
-                      nb_alloc, k, d_thist.as<u32>(), nullptr, nullptr, st);
+                      nb_alloc, k, d_thist.as<u32>(), nullptr, nullptr, tile_pos, st);
     c->prof_end();
     c->prof_begin(KC_BUCKET_PLAN);
     kh_launch_col_totals(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_tot.as<u64>(), st);
@@ -551,7 +562,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     c->prof_end();
     c->prof_begin(KC_EXTRACT_SCATTER);
     kh_launch_extract(W, true, d_seq.as<u8>(), d_segs.as<KhSeg>(), d_tiles.as<KhTile>(), ntiles,
-                      nb_alloc, k, d_thist.as<u32>(), d_bstart.as<u64>(), d_part.b->p, st);
+                      nb_alloc, k, d_thist.as<u32>(), d_bstart.as<u64>(), d_part.b->p, tile_pos, st);
     c->prof_end();
 
     // ---- pass C

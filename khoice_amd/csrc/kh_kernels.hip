@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
                                                 const KhTile* __restrict__ tiles, u32 nb_alloc,
                                                 int k, u32* __restrict__ thist,
                                                 const u64* __restrict__ bstart,
-                                                KmerKey<W>* __restrict__ part) {
+                                                KmerKey<W>* __restrict__ part, u32 tile_pos) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     u32* cur = reinterpret_cast<u32*>(lds_raw);
     u32* code = cur + nb_alloc;
@@ -275,10 +275,11 @@ __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
     if (SCATTER) part_base = bstart[sg.bucket_base];
 
     const Roller<W> roller(k);
-    const u64 tile_pos0 = (u64)t.tile_in_seg * KH_TILE;
+    const u64 tile_pos0 = (u64)t.tile_in_seg * tile_pos;
     constexpr int PPT = KH_SUBTILE / 256;   // 32 start positions per thread
+    const int subtiles = (int)(tile_pos / KH_SUBTILE);   // host: tile_pos is a multiple of 2 * KH_SUBTILE
 
-    for (int sub = 0; sub < KH_SUBTILES_PER_TILE; ++sub) {
+    for (int sub = 0; sub < subtiles; ++sub) {
         const u64 p0 = tile_pos0 + (u64)sub * KH_SUBTILE;
         if (p0 >= sg.npos) break;   // uniform over the block
         __syncthreads();            // cursor init done / previous sub-tile fully consumed
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
                                                           u32 nb_alloc, int k,
                                                           const u32* __restrict__ thist,
                                                           const u64* __restrict__ bstart,
-                                                          KmerKey<W>* __restrict__ part) {
+                                                          KmerKey<W>* __restrict__ part, u32 tile_pos) {
     using G = StageGeo<W>;
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     KmerKey<W>* stage = reinterpret_cast<KmerKey<W>*>(lds_raw);                      // [SUB]
@@ -349,10 +350,11 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
     for (u32 i = tid; i < nb; i += NT) cur[i] = row[i];
     const u64 part_base = bstart[sg.bucket_base];
     const Roller<W> roller(k);
-    const u64 tile_pos0 = (u64)t.tile_in_seg * KH_TILE;
+    const u64 tile_pos0 = (u64)t.tile_in_seg * tile_pos;
     const u32 per = (nb + NT - 1) / NT;   // scan entries per thread (host guarantees <= 4)
+    const int rounds = (int)(tile_pos / (u32)G::SUB);
 
-    for (int sb = 0; sb < G::ROUNDS; ++sb) {
+    for (int sb = 0; sb < rounds; ++sb) {
         const u64 p0 = tile_pos0 + (u64)sb * G::SUB;
         if (p0 >= sg.npos) break;   // uniform over the block
         __syncthreads();            // previous round fully flushed, cursors advanced
@@ -433,29 +435,53 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
     }
 }
 
-// column totals of the (tile x bucket) histogram matrix: one thread per (segment, bucket)
-__global__ void k_col_totals(const KhSeg* __restrict__ segs, const u32* __restrict__ thist,
-                             u64* __restrict__ tot) {
+// Column totals of the (tile x bucket) histogram matrix and, after the bucket starts are known,
+// the per-tile write cursors.  Block = 64 buckets x KH_COL_TY tile groups: lanes run over buckets
+// (coalesced rows), the tile groups split a segment's tiles into contiguous ranges, so that a
+// single genome cut into a few hundred small tiles (the per-call path) is not one long serial
+// walk per bucket.
+constexpr u32 KH_COL_TY = 8;
+__global__ __launch_bounds__(64 * KH_COL_TY) void k_col_totals(const KhSeg* __restrict__ segs,
+                                                              const u32* __restrict__ thist, u64* __restrict__ tot) {
+    __shared__ u64 part_sum[KH_COL_TY][64];
     const KhSeg sg = segs[blockIdx.y];
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= sg.nbuckets) return;
+    const u32 b = blockIdx.x * 64 + threadIdx.x, ty = threadIdx.y;
+    const u32 t0 = (u32)((u64)sg.ntiles * ty / KH_COL_TY), t1 = (u32)((u64)sg.ntiles * (ty + 1) / KH_COL_TY);
     u64 s = 0;
-    for (u32 t = 0; t < sg.ntiles; ++t) s += thist[sg.thist_base + (u64)t * sg.nbuckets + b];
-    tot[sg.bucket_base + b] = s;
+    if (b < sg.nbuckets)
+        for (u32 t = t0; t < t1; ++t) s += thist[sg.thist_base + (u64)t * sg.nbuckets + b];
+    part_sum[ty][threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && b < sg.nbuckets) {
+        u64 a = 0;
+        for (u32 y = 0; y < KH_COL_TY; ++y) a += part_sum[y][threadIdx.x];
+        tot[sg.bucket_base + b] = a;
+    }
 }
 // turn per-tile counts into per-tile write cursors, relative to the segment's first bucket
-__global__ void k_col_offsets(const KhSeg* __restrict__ segs, u32* __restrict__ thist,
-                              const u64* __restrict__ bstart, const u32* __restrict__ rank,
-                              const u64* __restrict__ seg_out_base, KhBucketWork* __restrict__ work) {
+__global__ __launch_bounds__(64 * KH_COL_TY) void k_col_offsets(const KhSeg* __restrict__ segs, u32* __restrict__ thist,
+                                                               const u64* __restrict__ bstart, const u32* __restrict__ rank,
+                                                               const u64* __restrict__ seg_out_base,
+                                                               KhBucketWork* __restrict__ work) {
+    __shared__ u64 part_sum[KH_COL_TY][64];
     const KhSeg sg = segs[blockIdx.y];
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= sg.nbuckets) return;
-    // pass C's work item of this bucket, at its place in the interleaved start order
+    const u32 b = blockIdx.x * 64 + threadIdx.x, ty = threadIdx.y;
+    const bool live = b < sg.nbuckets;
+    const u32 t0 = (u32)((u64)sg.ntiles * ty / KH_COL_TY), t1 = (u32)((u64)sg.ntiles * (ty + 1) / KH_COL_TY);
+    u64 s = 0;
+    if (live)
+        for (u32 t = t0; t < t1; ++t) s += thist[sg.thist_base + (u64)t * sg.nbuckets + b];
+    part_sum[ty][threadIdx.x] = s;
+    __syncthreads();
+    if (!live) return;
     const u32 gb = sg.bucket_base + b;
     const u64 lo = bstart[gb];
-    work[rank[gb]] = KhBucketWork{lo, seg_out_base[blockIdx.y], (u32)(bstart[gb + 1] - lo), sg.nbuckets, b, gb};
+    // pass C's work item of this bucket, at its place in the interleaved start order
+    if (ty == 0)
+        work[rank[gb]] = KhBucketWork{lo, seg_out_base[blockIdx.y], (u32)(bstart[gb + 1] - lo), sg.nbuckets, b, gb};
     u64 running = lo - bstart[sg.bucket_base];
-    for (u32 t = 0; t < sg.ntiles; ++t) {
+    for (u32 y = 0; y < ty; ++y) running += part_sum[y][threadIdx.x];
+    for (u32 t = t0; t < t1; ++t) {
         const u64 at = sg.thist_base + (u64)t * sg.nbuckets + b;
         const u32 c = thist[at];
         thist[at] = (u32)running;
@@ -2204,7 +2230,7 @@ template <class K> static void allow_lds(K kern, size_t bytes) {
 
 void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, const KhTile* tiles,
                        u32 ntiles, u32 nb_alloc, int k, u32* thist, const u64* bstart, void* part,
-                       hipStream_t st) {
+                       u32 tile_pos, hipStream_t st) {
     if (!ntiles) return;
     if (scatter && nb_alloc <= 4 * KH_ST_THREADS && kh_extract_staged_lds_bytes(W, nb_alloc) <= 160 * 1024 &&
         !getenv("KHOICE_DIRECT_SCATTER")) {
@@ -2212,11 +2238,11 @@ void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, co
         if (W == 1) {
             allow_lds(k_extract_staged<1>, lds2);
             hipLaunchKernelGGL(k_extract_staged<1>, dim3(ntiles), dim3(KH_ST_THREADS), lds2, st, seq, segs, tiles,
-                               nb_alloc, k, thist, bstart, reinterpret_cast<KmerKey<1>*>(part));
+                               nb_alloc, k, thist, bstart, reinterpret_cast<KmerKey<1>*>(part), tile_pos);
         } else {
             allow_lds(k_extract_staged<2>, lds2);
             hipLaunchKernelGGL(k_extract_staged<2>, dim3(ntiles), dim3(KH_ST_THREADS), lds2, st, seq, segs, tiles,
-                               nb_alloc, k, thist, bstart, reinterpret_cast<KmerKey<2>*>(part));
+                               nb_alloc, k, thist, bstart, reinterpret_cast<KmerKey<2>*>(part), tile_pos);
         }
         return;
     }
@@ -2226,7 +2252,7 @@ void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, co
         allow_lds(k_extract<WW, SC>, lds);                                                      \
         hipLaunchKernelGGL((k_extract<WW, SC>), dim3(ntiles), dim3(256), lds, st, seq, segs,    \
                            tiles, nb_alloc, k, thist, bstart,                                   \
-                           reinterpret_cast<KmerKey<WW>*>(part));                               \
+                           reinterpret_cast<KmerKey<WW>*>(part), tile_pos);                     \
     } while (0)
     if (W == 1) { if (scatter) KH_EX(1, true); else KH_EX(1, false); }
     else        { if (scatter) KH_EX(2, true); else KH_EX(2, false); }
@@ -2236,13 +2262,13 @@ void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, co
 void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* thist, u64* tot,
                           hipStream_t st) {
     if (!nseg || !max_nb) return;
-    hipLaunchKernelGGL(k_col_totals, dim3((max_nb + 255) / 256, nseg), dim3(256), 0, st, segs,
+    hipLaunchKernelGGL(k_col_totals, dim3((max_nb + 63) / 64, nseg), dim3(64, KH_COL_TY), 0, st, segs,
                        thist, tot);
 }
 void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
                            const u32* rank, const u64* seg_out_base, KhBucketWork* work, hipStream_t st) {
     if (!nseg || !max_nb) return;
-    hipLaunchKernelGGL(k_col_offsets, dim3((max_nb + 255) / 256, nseg), dim3(256), 0, st, segs,
+    hipLaunchKernelGGL(k_col_offsets, dim3((max_nb + 63) / 64, nseg), dim3(64, KH_COL_TY), 0, st, segs,
                        thist, bstart, rank, seg_out_base, work);
 }
 size_t kh_exscan_tmp_words(u64 n) { return (size_t)((n + KH_SCAN_TILE - 1) / KH_SCAN_TILE) + 1; }

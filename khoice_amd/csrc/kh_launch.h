@@ -128,7 +128,7 @@ size_t kh_sort_lds_bytes(int W, u32 cap, bool pay);
 
 void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, const KhTile* tiles,
                        u32 ntiles, u32 nb_alloc, int k, u32* thist, const u64* bstart, void* part,
-                       hipStream_t st);
+                       u32 tile_pos, hipStream_t st);   // tile_pos: k-mer positions per workgroup, a multiple of 16384
 void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* thist, u64* tot,
                           hipStream_t st);
 void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
