@@ -361,11 +361,14 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
         load_codes<NT>(sg.seq, sg.len, p0, code, bad16, (u32)G::CODE_WORDS);
         for (u32 i = tid; i <= nb; i += NT) sub[i] = 0;
         __syncthreads();
-        // ---- A: extract; the key of this thread's start position j is staged at NT*j + tid
+        // ---- A: extract; the thread's keys stay in registers until they are placed (phase C/D)
         u32 vm = 0;   // which of the PPT start positions gave a key
+        KmerKey<W> key[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) key[j] = key_zero<W>();
         extract_positions<W, PPT>(code, bad16, (u32)PPT * tid, k, roller, [&](int j, const KmerKey<W>& can) {
-            stage[NT * (u32)j + tid] = can;   // position-major: conflict-free, and
-            vm |= 1u << j;                     // phase C reads back exactly these
+            key[j] = can;
+            vm |= 1u << j;
             atomicAdd(&sub[kh_slot<W>(can, k, nb)], 1u);
         });
         __syncthreads();
@@ -392,24 +395,17 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
             if (tid == NT - 1) sub[nb] = run;   // total staged keys (threads past nb add nothing)
         }
         __syncthreads();
-        // ---- C/D: in-place counting sort by bucket through registers
+        // ---- C/D: counting sort by bucket, registers -> staging array
         {
-            KmerKey<W> key[PPT];
-            u32 pos2[PPT / 2];
+            u32 at[PPT];
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
-                key[j] = key_zero<W>();
-                u32 at = 0;
-                if (vm & (1u << j)) {
-                    key[j] = stage[NT * j + tid];
-                    at = atomicAdd(&sub[kh_slot<W>(key[j], k, nb)], 1u);
-                }
-                if (j & 1) pos2[j >> 1] |= at << 16; else pos2[j >> 1] = at;
+                at[j] = 0;
+                if (vm & (1u << j)) at[j] = atomicAdd(&sub[kh_slot<W>(key[j], k, nb)], 1u);
             }
-            __syncthreads();
 #pragma unroll
             for (int j = 0; j < PPT; ++j)
-                if (vm & (1u << j)) stage[(pos2[j >> 1] >> (16 * (j & 1))) & 0xffffu] = key[j];
+                if (vm & (1u << j)) stage[at[j]] = key[j];
         }
         __syncthreads();
         // ---- E: flush; sub[b] now holds the END of bucket b's staged run

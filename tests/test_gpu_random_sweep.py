@@ -78,3 +78,22 @@ def test_exp1_and_set_operations_on_random_shapes(eng, seed):
         kk, cc = x.download_sorted()
         wk, wc = wx.arrays()
         assert (kk == wk).all() and (cc == wc).all()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fused_path_on_random_shapes(eng, seed):
+    """The same shapes through the fused form (no group sets requested: grid-mode build + tagged
+    union, in batches when a shape has more than 64 genomes) — histograms, distinct counts and the
+    emitted across-group set against the C restatement."""
+    k, seqs, group_of = draw_case(seed)
+    cs = random.Random(seed).choice([5000, 3, 255])
+    want = CO.exp1(seqs, group_of, k, cs=cs, hist_len=300)
+    got = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=300)
+    assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+    assert (got["within_hist"] == want["within_hist"]).all()
+    assert (got["across_hist"] == want["across_hist"]).all()
+    got2 = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=300, want_across_set=True)
+    assert (got2["across_hist"] == want["across_hist"]).all()
+    keys, counts = got2["across_set"].download_sorted()
+    assert keys.shape[0] == int(want["across_hist"].sum())
+    assert (np.bincount(np.minimum(counts, 299), minlength=300) == want["across_hist"]).all()
