@@ -560,10 +560,20 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     kh_launch_col_offsets(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(), d_rank,
                           d_out_base, d_work.as<KhBucketWork>(), st);
     c->prof_end();
+#ifdef KH_STAMPS
+    Tmp d_stamps_b;
+    TMP_ALLOC(d_stamps_b, c, 128 * (u64)std::max<u32>(1, ntiles));
+    HIPCHK(hipMemsetAsync(d_stamps_b.b->p, 0, 128 * (u64)std::max<u32>(1, ntiles), st));
+    kh_debug_set_stamps(d_stamps_b.as<u64>());
+#endif
     c->prof_begin(KC_EXTRACT_SCATTER);
     kh_launch_extract(W, true, d_seq.as<u8>(), d_segs.as<KhSeg>(), d_tiles.as<KhTile>(), ntiles,
                       nb_alloc, k, d_thist.as<u32>(), d_bstart.as<u64>(), d_part.b->p, tile_pos, st);
     c->prof_end();
+#ifdef KH_STAMPS
+    report_stamps(c, "extract_scatter (last round of a tile: decode / extract / scan / place / flush / - / - / cursors)", d_stamps_b.b, ntiles);
+    kh_debug_set_stamps(nullptr);
+#endif
 
     // ---- pass C
     KhLookback lb;

@@ -156,6 +156,50 @@ __device__ __forceinline__ void load_codes(const u8* __restrict__ sbase, const u
     }
 }
 
+// The same in two steps, so that the global load of the NEXT round can be in flight while the
+// current one is processed: ki_fetch -> registers (up to two words per thread), ki_store -> LDS.
+struct CodeFetch { uint4 v[2]; u32 left[2]; };   // left: valid bytes of the word (0: past the end, >= 16: whole)
+template <u32 NT>
+__device__ __forceinline__ void fetch_codes(const u8* __restrict__ sbase, const u64 len, const u64 p0, const u32 nwords,
+                                            CodeFetch& f) {
+#pragma unroll
+    for (u32 r = 0; r < 2; ++r) {
+        const u32 w = threadIdx.x + r * NT;
+        f.left[r] = 0;
+        f.v[r] = make_uint4(0, 0, 0, 0);
+        if (w < nwords) {
+            const u64 b0 = p0 + 16ull * w;
+            if (b0 < len) {
+                const u64 left = len - b0;
+                f.left[r] = left >= 16 ? 16u : (u32)left;
+                if (left >= 16) {
+                    f.v[r] = *reinterpret_cast<const uint4*>(sbase + b0);
+                } else {   // last, partial word of the sequence: never touch bytes past its end
+                    u32 w4[4] = {0, 0, 0, 0};
+                    for (u32 i = 0; i < (u32)left; ++i) w4[i >> 2] |= (u32)sbase[b0 + i] << (8 * (i & 3));
+                    f.v[r] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+            }
+        }
+    }
+}
+template <u32 NT>
+__device__ __forceinline__ void store_codes(const CodeFetch& f, u32* code, u16* bad16, const u32 nwords) {
+#pragma unroll
+    for (u32 r = 0; r < 2; ++r) {
+        const u32 w = threadIdx.x + r * NT;
+        if (w < nwords) {
+            u32 codes = 0, bad = 0xffffu;
+            if (f.left[r]) {
+                decode16(f.v[r], codes, bad);
+                if (f.left[r] < 16) bad |= (0xffffu << f.left[r]) & 0xffffu;
+            }
+            code[w] = codes;
+            bad16[w] = (u16)bad;
+        }
+    }
+}
+
 template <int W> struct Roller;
 template <> struct Roller<1> {
     u64 mask, top_shift;
@@ -354,13 +398,18 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
     const u32 per = (nb + NT - 1) / NT;   // scan entries per thread (host guarantees <= 4)
     const int rounds = (int)(tile_pos / (u32)G::SUB);
 
+    static_assert(G::CODE_WORDS <= 2 * (int)NT, "two code words per thread");
+    CodeFetch pre;
+    fetch_codes<NT>(sg.seq, sg.len, tile_pos0, (u32)G::CODE_WORDS, pre);
     for (int sb = 0; sb < rounds; ++sb) {
         const u64 p0 = tile_pos0 + (u64)sb * G::SUB;
         if (p0 >= sg.npos) break;   // uniform over the block
         __syncthreads();            // previous round fully flushed, cursors advanced
-        load_codes<NT>(sg.seq, sg.len, p0, code, bad16, (u32)G::CODE_WORDS);
+        KH_STAMP(0, 0);
+        store_codes<NT>(pre, code, bad16, (u32)G::CODE_WORDS);   // fetched while the previous round was placed and flushed
         for (u32 i = tid; i <= nb; i += NT) sub[i] = 0;
         __syncthreads();
+        KH_STAMP(0, 1);
         // ---- A: extract; the thread's keys stay in registers until they are placed (phase C/D)
         u32 vm = 0;   // which of the PPT start positions gave a key
         KmerKey<W> key[PPT];
@@ -372,6 +421,10 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
             atomicAdd(&sub[kh_slot<W>(can, k, nb)], 1u);
         });
         __syncthreads();
+        KH_STAMP(0, 2);
+        // the next round's bases: requested now, decoded at the top of the next round (a bare
+        // HBM round trip at the start of every round was a fifth of the round)
+        if (sb + 1 < rounds && p0 + G::SUB < sg.npos) fetch_codes<NT>(sg.seq, sg.len, p0 + G::SUB, (u32)G::CODE_WORDS, pre);
         // ---- B: exclusive scan of the bucket counts, in place (sub[b] = first staged index)
         {
             u32 c[4], sum = 0;
@@ -395,6 +448,7 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
             if (tid == NT - 1) sub[nb] = run;   // total staged keys (threads past nb add nothing)
         }
         __syncthreads();
+        KH_STAMP(0, 3);
         // ---- C/D: counting sort by bucket, registers -> staging array
         {
             u32 at[PPT];
@@ -408,26 +462,45 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
                 if (vm & (1u << j)) stage[at[j]] = key[j];
         }
         __syncthreads();
-        // ---- E: flush; sub[b] now holds the END of bucket b's staged run
+        KH_STAMP(0, 4);
+        // ---- E: flush; sub[b] now holds the END of bucket b's staged run.  Two batches of PPT / 2:
+        // all key reads, then all cursor reads, then the stores (two dependent LDS round trips per
+        // batch instead of per key)
         {
             const u32 nvalid = sub[nb];
-#pragma unroll 4
-            for (int j = 0; j < PPT; ++j) {
-                const u32 p = NT * j + tid;
-                if (p < nvalid) {
-                    const KmerKey<W> key = stage[p];
-                    const u32 b = kh_slot<W>(key, k, nb);
-                    const u32 first = b ? sub[b - 1] : 0u;
+            constexpr int HB = PPT / 2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                KmerKey<W> fk[HB];
+                u32 fb2[HB], first[HB], cb[HB];
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    const u32 p = NT * (u32)(h * HB + j) + tid;
+                    fk[j] = stage[p < nvalid ? p : 0];
+                }
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    fb2[j] = kh_slot<W>(fk[j], k, nb);
+                    first[j] = fb2[j] ? sub[fb2[j] - 1] : 0u;
+                    cb[j] = cur[fb2[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    const u32 p = NT * (u32)(h * HB + j) + tid;
 #ifndef KH_DIAG_NO_SCATTER_STORE   // diagnostic builds only: how long pass B takes without its stores
-                    part[part_base + cur[b] + (p - first)] = key;
+                    if (p < nvalid) part[part_base + cb[j] + (p - first[j])] = fk[j];
 #else
-                    if (key.lo == 0x123456789abcdefull && b == 0xffffffffu) part[0] = key;
+                    if (p < nvalid && fk[j].lo == 0x123456789abcdefull && fb2[j] == 0xffffffffu) part[0] = fk[j];
 #endif
                 }
             }
         }
         __syncthreads();
+        KH_STAMP(0, 5);
+        KH_STAMP(0, 6);
+        KH_STAMP(0, 7);
         for (u32 b = tid; b < nb; b += NT) cur[b] += sub[b] - (b ? sub[b - 1] : 0u);
+        KH_STAMP(0, 8);
     }
 }
 
