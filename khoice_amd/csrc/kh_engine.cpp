@@ -385,8 +385,9 @@ struct GridBuild {
     kh_ctx* c = nullptr;
     u32 fan = 1;            // in: largest group (sets the slot fill of the tagged union)
     u32 cap = 0;            // in: slot capacity of the tagged union
+    u32 wave = 0, nwaves = 1;   // in: key-range wave (KhSeg::nb_virtual / b_first): this build keeps slice `wave` of `nwaves`
     u32 nb = 0, S = 0, nb_total = 0;
-    u64 total_pos = 0, bases = 0;
+    u64 total_pos = 0, bases = 0, key_cap = 0;   // key_cap: records the key arrays of this build can hold
     DevBuf *okeys = nullptr, *bstart = nullptr, *off = nullptr, *distinct = nullptr, *lb = nullptr;
     void* pin = nullptr;    // plan staging: must outlive the asynchronous upload
     size_t pin_bytes = 0;
@@ -423,9 +424,12 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         if (const char* ev = getenv("KHOICE_TILE_POS")) tile_pos = std::max<u32>(2 * KH_SUBTILE, (u32)strtoul(ev, nullptr, 10) / (2 * KH_SUBTILE) * (2 * KH_SUBTILE));
     }
     u64 grid_nb = 1;   // grid mode: one bucket grid for every sequence, sized by the longest
-    if (grid)
+    const u32 nwaves = grid ? std::max<u32>(1, grid->nwaves) : 1u;
+    if (grid) {
+        const u64 per = (u64)mean * nwaves;   // a wave keeps 1/nwaves of every genome's keys
         for (int i = 0; i < nseq; ++i)
-            if (lens[i] >= (u64)k) grid_nb = std::max<u64>(grid_nb, (lens[i] - k + 1 + mean - 1) / mean);
+            if (lens[i] >= (u64)k) grid_nb = std::max<u64>(grid_nb, (lens[i] - k + 1 + per - 1) / per);
+    }
     for (int i = 0; i < nseq; ++i) {
         KhSeg& s = segs[i];
         s.seq = nullptr;
@@ -440,6 +444,8 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
                            i, (unsigned long long)s.npos,
                            (unsigned long long)KH_MAX_BUCKETS_PER_SEG * mean);
         s.nbuckets = (u32)want_b;
+        s.nb_virtual = (u32)want_b * nwaves;
+        s.b_first = grid ? grid->wave * (u32)want_b : 0u;
         s.bucket_base = nb_total;
         s.ntiles = (u32)((s.npos + tile_pos - 1) / tile_pos);
         s.tile_base = (u32)tiles.size();
@@ -466,7 +472,11 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     TMP_ALLOC(d_bstart, c, 8 * ((u64)nb_total + 1));
     Tmp d_scan;
     TMP_ALLOC(d_scan, c, 8 * kh_exscan_tmp_words(nb_total));
-    TMP_ALLOC(d_part, c, kb * std::max<u64>(1, total_pos));
+    // a key-range wave keeps about total_pos / nwaves keys — how many exactly is known after the
+    // bucket plan, so its partition and output arrays are allocated there (one extra wait per wave)
+    const bool late_alloc = nwaves > 1;
+    u64 key_cap = std::max<u64>(1, total_pos);
+    if (!late_alloc) TMP_ALLOC(d_part, c, kb * key_cap);
     TMP_ALLOC(d_lb, c, 8 * (u64)nb_total + 64);
     KhGrid kgrid{nullptr, nullptr, 0, 0};
     if (grid) {
@@ -476,7 +486,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         const double zg = 5.0 * std::sqrt((double)std::max<u32>(1, grid->fan));
         const double x = 0.5 * (-zg + std::sqrt(zg * zg + 4.0 * (double)grid->cap));
         const u64 target = std::max<u64>(16, std::min<u64>((u64)grid->cap * 92 / 100, (u64)(x * x)));
-        const u64 per_bucket = (total_pos + grid_nb - 1) / grid_nb;       // keys of one bucket over all genomes
+        const u64 per_bucket = (total_pos + grid_nb * nwaves - 1) / (grid_nb * nwaves);   // keys of one bucket over all genomes
         grid->S = (u32)std::max<u64>(1, (per_bucket + target - 1) / target);
         if (grid->S > (u32)KH_FINE_BINS / 2 || grid_nb * grid->S > 0x7fffffffull)
             return kh_fail(KH_E_ARG, "grid build: %llu sub-ranges per bucket", (unsigned long long)grid->S);
@@ -492,14 +502,14 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         kgrid = KhGrid{reinterpret_cast<u16*>(grid->off->p), reinterpret_cast<unsigned long long*>(grid->distinct->p),
                        grid->S, grid->nb};
     }
-    DevBuf* okeys = c->buf_alloc(kb * std::max<u64>(1, total_pos));
-    if (!okeys) return kh_fail(KH_E_NOMEM, "device allocation failed (output keys)");
+    DevBuf* okeys = late_alloc ? nullptr : c->buf_alloc(kb * key_cap);
+    if (!late_alloc && !okeys) return kh_fail(KH_E_NOMEM, "device allocation failed (output keys)");
     DevBuf* ocnt = nullptr;
     if (with_counts) {
         ocnt = c->buf_alloc(4 * std::max<u64>(1, total_pos));
         if (!ocnt) { buf_unref(okeys); return kh_fail(KH_E_NOMEM, "device allocation failed (counts)"); }
     }
-    struct Guard { DevBuf *a, *b; ~Guard() { buf_unref(a); buf_unref(b); } } guard{okeys, ocnt};
+    struct Guard { DevBuf *&a, *&b; ~Guard() { buf_unref(a); buf_unref(b); } } guard{okeys, ocnt};
 
     // device-resident, 16-byte aligned inputs are read in place; anything else is packed into
     // the aligned batch buffer first
@@ -560,6 +570,15 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     kh_launch_col_offsets(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(), d_rank,
                           d_out_base, d_work.as<KhBucketWork>(), st);
     c->prof_end();
+    if (late_alloc) {
+        u64 nkeys = 0;
+        HIPCHK(hipMemcpyAsync(&nkeys, d_bstart.as<u64>() + nb_total, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        key_cap = std::max<u64>(1, nkeys);
+        TMP_ALLOC(d_part, c, kb * key_cap);
+        okeys = c->buf_alloc(kb * key_cap);
+        if (!okeys) return kh_fail(KH_E_NOMEM, "device allocation failed (output keys)");
+    }
 #ifdef KH_STAMPS
     Tmp d_stamps_b;
     TMP_ALLOC(d_stamps_b, c, 128 * (u64)std::max<u32>(1, ntiles));
@@ -598,6 +617,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     kh_debug_set_stamps(nullptr);
 #endif
     if (grid) {   // hand the device state over; the caller synchronises
+        grid->key_cap = key_cap;
         buf_ref(okeys); grid->okeys = okeys;
         buf_ref(d_bstart.b); grid->bstart = d_bstart.b;
         buf_ref(d_lb.b); grid->lb = d_lb.b;
@@ -1477,7 +1497,7 @@ static int group_union_incremental(kh_ctx* c, const std::vector<int>& members, c
 static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                       const int* group_of, int ngroups, int k, u32 cs, uint64_t* within_hist,
                       uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, kh_set** across_set,
-                      bool* done) {
+                      bool* done, u32 nwaves = 1) {
     *done = false;
     const int W = k <= 32 ? 1 : 2;
     if (nseq > KH_TAG_MAX_OPS || ngroups > KH_TAG_MAX_OPS) return KH_OK;
@@ -1512,16 +1532,26 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     HIPCHK(hipSetDevice(c->dev));
     hipStream_t st = c->st;
 
+    std::vector<u64> bins(nbins, 0), dist_acc(nseq, 0);
+    const bool emit = across_set != nullptr;
+    std::vector<kh_set*> wave_sets;   // emitted across-group sets, one per wave (disjoint, ascending key ranges)
+    auto drop_sets = [&]() { for (auto* s : wave_sets) kh_set_free(s); wave_sets.clear(); };
+    struct SetsGuard { std::vector<kh_set*>& v; ~SetsGuard() { for (auto* s : v) kh_set_free(s); } } sets_guard{wave_sets};
+    for (u32 wave = 0; wave < nwaves; ++wave) {
     GridBuild gb;
     gb.fan = fan;
+    gb.wave = wave;
+    gb.nwaves = nwaves;
     gb.cap = W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2;
     bool cap_hit = false, again = false;
-    KHCHK(build_once(c, nseq, pseq.data(), plen.data(), on_device, k, 1, KH_NO_MAX, KH_KMC_DEFAULT_CS, 0, mean,
-                     nullptr, &cap_hit, &again, &gb));
+    {
+        const int br = build_once(c, nseq, pseq.data(), plen.data(), on_device, k, 1, KH_NO_MAX, KH_KMC_DEFAULT_CS, 0, mean,
+                                  nullptr, &cap_hit, &again, &gb);
+        if (br != KH_OK) { drop_sets(); return br; }
+    }
 
     // ---- tagged union queued behind the build
     const u32 nslots = gb.nb * gb.S;
-    const bool emit = across_set != nullptr;
     const u32 grid = nslots;
     const u32 reps = std::min<u32>(256, std::max<u32>(1, grid));
     // workspace: [hist: reps x nbins u64][ctl: 8 u32][out_n u64][ginfo: 64 u32][descriptors: nslots u64 when emitting]
@@ -1551,8 +1581,8 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     DevBuf *okeys = nullptr, *ocnt = nullptr;
     struct OutGuard { DevBuf*& a; DevBuf*& b; ~OutGuard() { buf_unref(a); buf_unref(b); } } og{okeys, ocnt};
     if (emit) {
-        okeys = c->buf_alloc(8 * (size_t)W * std::max<u64>(1, gb.total_pos));
-        ocnt = c->buf_alloc(4 * std::max<u64>(1, gb.total_pos));
+        okeys = c->buf_alloc(8 * (size_t)W * std::max<u64>(1, gb.key_cap));
+        ocnt = c->buf_alloc(4 * std::max<u64>(1, gb.key_cap));
         if (!okeys || !ocnt) return kh_fail(KH_E_NOMEM, "device allocation failed (across-group set)");
     }
     KhTagJob job;
@@ -1564,6 +1594,7 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     job.ctl = reinterpret_cast<u32*>(wsp + 8 * hist_words);
     job.nb = gb.nb; job.S = gb.S; job.nops = (u32)nseq; job.nbins = nbins; job.abase = abase;
     job.ngroups = (u32)ngroups; job.reps = reps;
+    job.nbv = gb.nb * nwaves;
     job.binmul = (1u << 26) / ((KH_FINE_BINS + gb.S - 1) / gb.S);
     job.out_keys = emit ? okeys->p : nullptr;
     job.out_counts = emit ? reinterpret_cast<u32*>(ocnt->p) : nullptr;
@@ -1593,22 +1624,30 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     const u32 uerr = h_ctl[0];
     if ((cerr | uerr) & (KH_ERR_CAPACITY | KH_ERR_SPIN_TIMEOUT | KH_ERR_ORDER)) {
         c->stat.retries++;
+        drop_sets();
         return KH_OK;   // a bucket or a slot did not fit: the general path re-plans
     }
-    c->stat.bases += gb.bases;
+    if (wave == 0) { c->stat.bases += gb.bases; c->stat.builds += nseq; }
     c->stat.kmers += *h_nvalid;
-    c->stat.builds += nseq;
     c->stat.setops++;
     u64 dsum = 0;
     for (int i = 0; i < nseq; ++i) {
-        if (distinct_per_seq) distinct_per_seq[perm[i]] = h_distinct[i];
+        dist_acc[i] += h_distinct[i];
         dsum += h_distinct[i];
     }
     c->stat.distinct += dsum;
     c->stat.setop_in += dsum;
-    std::vector<u64> bins(nbins, 0);
     for (u32 r = 0; r < reps; ++r)
         for (u32 b = 0; b < nbins; ++b) bins[b] += h_hist[(size_t)r * nbins + b];
+    if (emit) {
+        const u64 n = *reinterpret_cast<const u64*>(h_ctl + 8);
+        buf_ref(okeys);
+        buf_ref(ocnt);
+        wave_sets.push_back(make_set(k, n, okeys, 0, ocnt, 0, 1, cs));
+    }
+    }   // waves
+    if (distinct_per_seq)
+        for (int i = 0; i < nseq; ++i) distinct_per_seq[perm[i]] = dist_acc[i];
     if (within_hist) {
         memset(within_hist, 0, 8 * (size_t)ngroups * hist_len);
         for (int g = 0; g < ngroups; ++g)
@@ -1623,11 +1662,15 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         for (int cnt = 1; cnt <= ngroups; ++cnt)
             across_hist[std::min<u32>((u32)cnt, hist_len - 1)] += bins[abase + cnt];
     }
-    if (emit) {
-        const u64 n = *reinterpret_cast<const u64*>(h_ctl + 8);
-        buf_ref(okeys);
-        buf_ref(ocnt);
-        *across_set = make_set(k, n, okeys, 0, ocnt, 0, 1, cs);
+    if (across_set) {
+        if (wave_sets.size() == 1) {
+            *across_set = wave_sets[0];
+            wave_sets.clear();
+        } else {   // the waves' sets cover disjoint key ranges: their union is their concatenation
+            const int r = kh_union_sum(c, wave_sets.data(), (int)wave_sets.size(), cs, across_set, nullptr, 0);
+            drop_sets();
+            if (r != KH_OK) return r;
+        }
     }
     *done = true;
     return KH_OK;
@@ -1667,18 +1710,27 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
             u64 acc_b = 0;
             int acc_n = 0, acc_g = 0, acc_bins = 0;
             for (int g = 0; g < ngroups && applicable; ++g) {
-                if (gcount[g] > KH_TAG_MAX_OPS || gbases[g] > fbudget || gcount[g] == 0) { applicable = false; break; }
+                if (gcount[g] > KH_TAG_MAX_OPS || gcount[g] == 0) { applicable = false; break; }
+                // (a batch above the memory budget is run as key-range waves, see below: groups are
+                // only split into batches by the width of the genome mask)
                 const bool fits = acc_n + gcount[g] <= KH_TAG_MAX_OPS && acc_g + 1 <= KH_TAG_MAX_OPS &&
-                                  acc_bins + gcount[g] + 1 + (acc_g + 2) <= KH_TAG_MAX_BINS && acc_b + gbases[g] <= fbudget;
+                                  acc_bins + gcount[g] + 1 + (acc_g + 2) <= KH_TAG_MAX_BINS &&
+                                  (acc_b + gbases[g] <= fbudget || acc_n == 0);
                 if (!fits) { batch_end.push_back(g); acc_b = 0; acc_n = acc_g = acc_bins = 0; }
                 acc_b += gbases[g]; acc_n += gcount[g]; acc_g += 1; acc_bins += gcount[g] + 1;
             }
             batch_end.push_back(ngroups);
         }
+        // a batch whose bases exceed the budget: key-range waves (HBM-spill partitioning of BASELINE
+        // configs[4]) — every wave re-extracts the batch's bases but keeps one slice of the key space,
+        // so the memory in flight is 1/waves of the keys and the histograms of the waves add up
+        auto waves_for = [&](u64 bases) -> u32 { return (u32)std::max<u64>(1, (bases + fbudget - 1) / fbudget); };
         if (applicable && batch_end.size() == 1) {
+            u64 all_bases = 0;
+            for (int g = 0; g < ngroups; ++g) all_bases += gbases[g];
             bool done = false;
             KHCHK(exp1_fused(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, within_hist, across_hist,
-                             hist_len, distinct_per_seq, across_set, &done));
+                             hist_len, distinct_per_seq, across_set, &done, waves_for(all_bases)));
             if (done) return KH_OK;
         } else if (applicable) {
             const bool want_across = across_hist || across_set;
@@ -1697,9 +1749,11 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
                 for (size_t j = 0; j < idx.size(); ++j) { bs[j] = seqs[idx[j]]; bl[j] = lens[idx[j]]; bg[j] = group_of[idx[j]] - g0; }
                 kh_set* aset = nullptr;
                 bool done = false;
+                u64 bbases = 0;
+                for (int g = g0; g < g1; ++g) bbases += gbases[g];
                 int r = exp1_fused(c, (int)idx.size(), bs.data(), bl.data(), on_device, bg.data(), g1 - g0, k, cs,
                                    within_hist ? within_hist + (size_t)g0 * hist_len : nullptr, nullptr, hist_len,
-                                   bd.data(), want_across ? &aset : nullptr, &done);
+                                   bd.data(), want_across ? &aset : nullptr, &done, waves_for(bbases));
                 if (r != KH_OK) { drop(); return r; }
                 if (!done) { ok = false; break; }
                 if (aset) asets.push_back(aset);

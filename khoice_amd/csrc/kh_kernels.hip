@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void k_extract(const u8* __restrict__ seq,
         load_codes<256>(sg.seq, sg.len, p0, code, bad16, (u32)KH_CODE_WORDS);
         __syncthreads();
         extract_positions<W, PPT>(code, bad16, (u32)PPT * tid, k, roller, [&](int, const KmerKey<W>& can) {
-            const u32 slot = kh_slot<W>(can, k, nb);
+            const u32 slot = kh_slot<W>(can, k, sg.nb_virtual) - sg.b_first;
+            if (slot >= nb) return;   // a key-range wave keeps its own slice of the key space only
             if (SCATTER) {
                 const u32 pos = atomicAdd(&cur[slot], 1u);
                 part[part_base + pos] = can;
@@ -415,10 +416,13 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
         KmerKey<W> key[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; ++j) key[j] = key_zero<W>();
+        const u32 nbv = sg.nb_virtual, b_first = sg.b_first;
         extract_positions<W, PPT>(code, bad16, (u32)PPT * tid, k, roller, [&](int j, const KmerKey<W>& can) {
+            const u32 slot = kh_slot<W>(can, k, nbv) - b_first;
+            if (slot >= nb) return;   // a key-range wave keeps its own slice of the key space only
             key[j] = can;
             vm |= 1u << j;
-            atomicAdd(&sub[kh_slot<W>(can, k, nb)], 1u);
+            atomicAdd(&sub[slot], 1u);
         });
         __syncthreads();
         KH_STAMP(0, 2);
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
                 at[j] = 0;
-                if (vm & (1u << j)) at[j] = atomicAdd(&sub[kh_slot<W>(key[j], k, nb)], 1u);
+                if (vm & (1u << j)) at[j] = atomicAdd(&sub[kh_slot<W>(key[j], k, nbv) - b_first], 1u);
             }
 #pragma unroll
             for (int j = 0; j < PPT; ++j)
@@ -480,7 +484,8 @@ __global__ __launch_bounds__(KH_ST_THREADS, 1) void k_extract_staged(const u8* _
                 }
 #pragma unroll
                 for (int j = 0; j < HB; ++j) {
-                    fb2[j] = kh_slot<W>(fk[j], k, nb);
+                    const u32 p = NT * (u32)(h * HB + j) + tid;
+                    fb2[j] = p < nvalid ? kh_slot<W>(fk[j], k, nbv) - b_first : 0u;
                     first[j] = fb2[j] ? sub[fb2[j] - 1] : 0u;
                     cb[j] = cur[fb2[j]];
                 }
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(64 * KH_COL_TY) void k_col_offsets(const KhSeg* __r
     const u64 lo = bstart[gb];
     // pass C's work item of this bucket, at its place in the interleaved start order
     if (ty == 0)
-        work[rank[gb]] = KhBucketWork{lo, seg_out_base[blockIdx.y], (u32)(bstart[gb + 1] - lo), sg.nbuckets, b, gb};
+        work[rank[gb]] = KhBucketWork{lo, seg_out_base[blockIdx.y], (u32)(bstart[gb + 1] - lo), sg.nb_virtual, b, gb};
     u64 running = lo - bstart[sg.bucket_base];
     for (u32 y = 0; y < ty; ++y) running += part_sum[y][threadIdx.x];
     for (u32 t = t0; t < t1; ++t) {
@@ -1937,9 +1942,9 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_uni
         // binmul stretches the widest slot over the KH_FINE_BINS bins.  A key from outside the slot
         // (corrupt index) lands in the last bin instead of outside the table.
         const u32 rel0 = kh_first_bin(f, S) << (32 - KH_FINE_BITS);
-        const u32 binmul = jb.binmul;
+        const u32 binmul = jb.binmul, nbv = jb.nbv;
         auto binfn = [=](const KmerKey<W>& key) -> u32 {
-            const u32 frac = (u32)((u64)kh_top32(key, k) * (u64)nb);
+            const u32 frac = (u32)((u64)kh_top32(key, k) * (u64)nbv);
             const u32 fb = (u32)(((u64)(frac - rel0) * (u64)binmul) >> 32);
             return fb < (u32)KH_FINE_BINS ? fb : (u32)KH_FINE_BINS - 1u;
         };

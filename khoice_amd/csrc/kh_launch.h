@@ -9,10 +9,16 @@ struct KhSeg {
     u64 len;          // bases (bytes)
     u64 npos;         // k-mer start positions: len >= k ? len-k+1 : 0
     u64 thist_base;   // index of tile 0 / bucket 0 in the tile-histogram matrix
-    u32 nbuckets;     // B_s
+    u32 nbuckets;     // B_s: buckets this build keeps (cursor rows, bucket arrays)
     u32 bucket_base;  // index of its first bucket in the global bucket arrays
     u32 tile_base;    // global index of its first tile
     u32 ntiles;
+    // Key-range waves (a build that keeps only one slice of the key space, kh_exp1_run under a memory
+    // budget): the key space is cut into nb_virtual equal-width buckets, of which this build keeps
+    // [b_first, b_first + nbuckets); keys of other buckets are dropped in passes A and B.  A build of
+    // the whole key space has nb_virtual == nbuckets and b_first == 0.
+    u32 nb_virtual;
+    u32 b_first;
 };
 struct KhTile { u32 seg; u32 tile_in_seg; };
 
@@ -26,7 +32,7 @@ struct KhBucketWork {
     u64 lo;         // first key of the bucket in the partition array
     u64 out_base;   // first output record of the bucket's segment
     u32 n;          // keys in the bucket
-    u32 nb;         // buckets of the segment (fine-bin scale)
+    u32 nb;         // equal-width buckets of the whole key space (the fine-bin scale; KhSeg::nb_virtual)
     u32 b;          // index of the bucket inside its segment = index in the segment's chain
     u32 gb;         // global bucket index (segment's chain starts at gb - b)
 };
@@ -102,6 +108,7 @@ struct KhTagJob {
     unsigned long long* hist;   // [reps][nbins]
     u32* ctl;                   // [0] error bits, [1] fullest slot seen
     u32 nb, S, nops, nbins, abase, ngroups, reps;
+    u32 nbv;                    // buckets of the whole key space (== nb unless the build was a key-range wave)
     u32 binmul;                 // 2^26 / (fine bins of the widest sub-range): in-slot fine-bin scale
     // optional ordered output (multi-GPU: the local across-group set, counter = groups holding the key)
     void* out_keys;
