@@ -385,6 +385,7 @@ struct GridBuild {
     kh_ctx* c = nullptr;
     u32 fan = 1;            // in: largest group (sets the slot fill of the tagged union)
     u32 cap = 0;            // in: slot capacity of the tagged union
+    double s_scale = 1.0;       // in: more sub-ranges per bucket than the estimate (retry after a slot overflow)
     u32 wave = 0, nwaves = 1;   // in: key-range wave (KhSeg::nb_virtual / b_first): this build keeps slice `wave` of `nwaves`
     u32 nb = 0, S = 0, nb_total = 0;
     u64 total_pos = 0, bases = 0, key_cap = 0;   // key_cap: records the key arrays of this build can hold
@@ -487,7 +488,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         const double x = 0.5 * (-zg + std::sqrt(zg * zg + 4.0 * (double)grid->cap));
         const u64 target = std::max<u64>(16, std::min<u64>((u64)grid->cap * 92 / 100, (u64)(x * x)));
         const u64 per_bucket = (total_pos + grid_nb * nwaves - 1) / (grid_nb * nwaves);   // keys of one bucket over all genomes
-        grid->S = (u32)std::max<u64>(1, (per_bucket + target - 1) / target);
+        grid->S = (u32)std::max<u64>(1, (u64)std::ceil((double)((per_bucket + target - 1) / target) * grid->s_scale));
         if (grid->S > (u32)KH_FINE_BINS / 2 || grid_nb * grid->S > 0x7fffffffull)
             return kh_fail(KH_E_ARG, "grid build: %llu sub-ranges per bucket", (unsigned long long)grid->S);
         grid->c = c;
@@ -1497,8 +1498,9 @@ static int group_union_incremental(kh_ctx* c, const std::vector<int>& members, c
 static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                       const int* group_of, int ngroups, int k, u32 cs, uint64_t* within_hist,
                       uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, kh_set** across_set,
-                      bool* done, u32 nwaves = 1) {
+                      bool* done, u32 nwaves = 1, double s_scale = 1.0, double* want_scale = nullptr) {
     *done = false;
+    if (want_scale) *want_scale = 0.0;
     const int W = k <= 32 ? 1 : 2;
     if (nseq > KH_TAG_MAX_OPS || ngroups > KH_TAG_MAX_OPS) return KH_OK;
     // operands in group-major order: the genomes of a group are consecutive bits of the mask
@@ -1542,6 +1544,7 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     gb.fan = fan;
     gb.wave = wave;
     gb.nwaves = nwaves;
+    gb.s_scale = s_scale;
     gb.cap = W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2;
     bool cap_hit = false, again = false;
     {
@@ -1625,7 +1628,11 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     if ((cerr | uerr) & (KH_ERR_CAPACITY | KH_ERR_SPIN_TIMEOUT | KH_ERR_ORDER)) {
         c->stat.retries++;
         drop_sets();
-        return KH_OK;   // a bucket or a slot did not fit: the general path re-plans
+        // a slot of the union held more records than fit (keys shared by many genomes, repeats): the
+        // kernel recorded its fullest slot, the caller may try again with that many more sub-ranges
+        if (want_scale && !(cerr & KH_ERR_CAPACITY) && (uerr & KH_ERR_CAPACITY) && !(uerr & KH_ERR_ORDER) && h_ctl[1] > gb.cap)
+            *want_scale = s_scale * 1.15 * (double)h_ctl[1] / (double)gb.cap;
+        return KH_OK;   // otherwise the general path re-plans
     }
     if (wave == 0) { c->stat.bases += gb.bases; c->stat.builds += nseq; }
     c->stat.kmers += *h_nvalid;
@@ -1729,9 +1736,15 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
             u64 all_bases = 0;
             for (int g = 0; g < ngroups; ++g) all_bases += gbases[g];
             bool done = false;
+            double scale = 0.0;
             KHCHK(exp1_fused(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, within_hist, across_hist,
-                             hist_len, distinct_per_seq, across_set, &done, waves_for(all_bases)));
+                             hist_len, distinct_per_seq, across_set, &done, waves_for(all_bases), 1.0, &scale));
             if (done) return KH_OK;
+            if (scale > 1.0 && scale < 16.0) {   // one more try with finer slots before the general path
+                KHCHK(exp1_fused(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, within_hist, across_hist,
+                                 hist_len, distinct_per_seq, across_set, &done, waves_for(all_bases), scale, nullptr));
+                if (done) return KH_OK;
+            }
         } else if (applicable) {
             const bool want_across = across_hist || across_set;
             std::vector<kh_set*> asets;

@@ -152,3 +152,16 @@ def test_fused_key_range_waves(eng, monkeypatch, k):
         assert (gk == rk).all() and (gc == rc).all()
         assert (with_set["within_hist"] == ref["within_hist"]).all()
     monkeypatch.delenv("KHOICE_WAVE_BASES")
+
+
+def test_fused_retries_with_finer_slots(eng):
+    """Forty one-genome groups of the SAME sequence: the slot fill is planned for keys that come in
+    single copies, every key comes in forty, so slots overflow; the fused path reads the fullest
+    slot the kernel recorded and tries once more with finer slots (the general path after that)."""
+    rng = random.Random(3)
+    base = random_dna(rng, 150_000).encode()
+    seqs, group_of = [base] * 40, list(range(40))
+    r0 = eng.stats()["retries"]
+    got, _ = check(eng, seqs, group_of, 31, hist_len=64)
+    assert eng.stats()["retries"] > r0
+    assert int(got["across_hist"][40]) == int(got["distinct_per_seq"][0])      # every k-mer is in all forty groups
