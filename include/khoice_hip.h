@@ -225,6 +225,22 @@ int kh_exp1_run(kh_ctx *ctx, int nseq, const uint8_t *const *seqs, const uint64_
                 uint64_t *within_hist, uint64_t *across_hist, uint32_t hist_len,
                 uint64_t *distinct_per_seq, kh_set **group_sets, kh_set **across_set);
 
+/* ---------------------------------------------------------------- multi-GPU exchange (RCCL over xGMI)
+ * Steps 7-8 of exp_type_1.smk:243-259 when the groups are sharded over several GPUs, one process
+ * per GPU: every rank runs kh_exp1_run on its own groups asking for `across_set` (counter = number
+ * of its groups holding the k-mer) and calls kh_across_exchange_histogram; the mixed key space is
+ * cut into nranks slots, slices travel by grouped ncclSend / ncclRecv (full mesh), the owner sums
+ * the counters (saturating at cs) and the histograms are all-reduced: every rank gets the global
+ * step_8 histogram.  kh_comm_unique_id is called on one rank and its 128 bytes handed to the others
+ * by whatever launched them (file, socket, MPI); RCCL is loaded on first use. */
+#define KH_COMM_ID_BYTES 128
+typedef struct kh_comm kh_comm;
+int kh_comm_unique_id(char id[KH_COMM_ID_BYTES]);
+int kh_comm_init(kh_ctx *ctx, int rank, int nranks, const char id[KH_COMM_ID_BYTES], kh_comm **out);
+void kh_comm_destroy(kh_comm *comm);
+int kh_across_exchange_histogram(kh_ctx *ctx, kh_comm *comm, const kh_set *local_across_set, uint32_t cs,
+                                 uint64_t *hist, uint32_t hist_len);
+
 /* host-side helpers exposed for tests (no device work) */
 void kh_mix_host(int k, const uint64_t *key_words, uint64_t *out_words);
 void kh_unmix_host(int k, const uint64_t *key_words, uint64_t *out_words);

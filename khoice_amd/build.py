@@ -23,7 +23,7 @@ BINDIR = os.path.join(ROOT, "bin")
 LIB = os.path.join(LIBDIR, "libkhoice_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["kh_kernels.hip", "kh_ingest.hip", "kh_engine.cpp", "kh_io.cpp"]
+HIP_SOURCES = ["kh_kernels.hip", "kh_ingest.hip", "kh_engine.cpp", "kh_io.cpp", "kh_comm.cpp"]
 HEADERS = ["kh_common.h", "kh_launch.h", "kh_engine.h", os.path.join(ROOT, "include", "khoice_hip.h")]
 CLIS = {"kmc": "kmc_main.cpp", "kmc_tools": "kmc_tools_main.cpp", "khoice_server": "kh_server_main.cpp"}
 CLI_COMMON = "kh_cli.cpp"
@@ -65,7 +65,7 @@ def build_library(force: bool = False) -> str:
     if force or _newer(LIB, objs):
         # --no-undefined: a launcher declared in kh_launch.h but not defined must fail the build,
         # not the first dlopen on the GPU box
-        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,--no-undefined", "-o", LIB] + objs + ["-lz"])
+        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,--no-undefined", "-o", LIB] + objs + ["-lz", "-ldl"])
     return LIB
 
 

@@ -95,6 +95,10 @@ def load_library(path: Optional[str] = None):
         "kh_exp1_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), u64p, C.c_int, C.POINTER(C.c_int), C.c_int,
                                   C.c_int, C.c_uint32, u64p, u64p, C.c_uint32, u64p, C.POINTER(vp),
                                   C.POINTER(vp)]),
+        "kh_comm_unique_id": (C.c_int, [C.c_char_p]),
+        "kh_comm_init": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]),
+        "kh_comm_destroy": (None, [vp]),
+        "kh_across_exchange_histogram": (C.c_int, [vp, vp, vp, C.c_uint32, u64p, C.c_uint32]),
         "kh_mix_host": (None, [C.c_int, u64p, u64p]),
         "kh_unmix_host": (None, [C.c_int, u64p, u64p]),
     }
@@ -118,7 +122,8 @@ ABI_SYMBOLS = [
     "kh_set_upload", "kh_set_device_ptrs", "kh_set_from_device", "kh_set_export_device",
     "kh_set_export_range", "kh_set_wrap_device", "kh_set_partition_bounds",
     "kh_sets_partition_bounds",
-    "kh_save", "kh_load", "kh_exp1_run", "kh_mix_host", "kh_unmix_host",
+    "kh_save", "kh_load", "kh_exp1_run", "kh_comm_unique_id", "kh_comm_init", "kh_comm_destroy",
+    "kh_across_exchange_histogram", "kh_mix_host", "kh_unmix_host",
 ]
 
 
@@ -480,6 +485,25 @@ class Engine:
         hist = np.zeros(hist_len, dtype=np.uint64)
         _check(self._lib.kh_table_histogram(self._ctx, table_ptr, cell_bytes, lo, hi, cs, _u64p(hist),
                                             hist_len))
+        return hist
+
+    # -- C-level RCCL exchange (what a caller without torch.distributed uses)
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(self._lib.kh_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank: int, nranks: int, uid: bytes):
+        out = C.c_void_p()
+        _check(self._lib.kh_comm_init(self._ctx, rank, nranks, uid, C.byref(out)))
+        return out
+
+    def comm_destroy(self, comm):
+        self._lib.kh_comm_destroy(comm)
+
+    def across_exchange_histogram(self, comm, local_across_set: KmerSet, cs: int, hist_len: int) -> np.ndarray:
+        hist = np.zeros(hist_len, dtype=np.uint64)
+        _check(self._lib.kh_across_exchange_histogram(self._ctx, comm, local_across_set._h, cs, _u64p(hist), hist_len))
         return hist
 
     def load(self, prefix: str) -> KmerSet:

@@ -32,3 +32,27 @@ def test_bench_self_launches_two_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
+
+
+def test_c_level_rccl_exchange_world_1():
+    """kh_comm_init / kh_across_exchange_histogram (the exchange behind the C ABI, RCCL loaded with
+    dlopen) at world size 1: the local across-group set goes through the all-gather of bounds, the
+    grouped send/recv (to itself), the counter-summing union and the all-reduce, and must give the
+    step_8 histogram the fused step computed directly.  (More ranks need more GPUs than this box has.)"""
+    from khoice_amd import build as kbuild
+    from khoice_amd import engine as E
+    from khoice_amd import synth
+    kbuild.build_library()
+    items = synth.species_set(4, 2, 150_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    with E.Engine(0) as eng:
+        for k in (31, 41):
+            res = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64, want_across_set=True)
+            comm = eng.comm_init(0, 1, eng.comm_unique_id())
+            try:
+                h = eng.across_exchange_histogram(comm, res["across_set"], 5000, 64)
+            finally:
+                eng.comm_destroy(comm)
+            assert (h == res["across_hist"]).all()
+            assert int(h[2:].sum()) > 0
