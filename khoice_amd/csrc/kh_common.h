@@ -147,7 +147,6 @@ constexpr int KH_LHIST_BINS = 512;          // LDS histogram bins fused into set
 #define KH_TUNE_HASH_ROUNDS 3
 #endif
 constexpr int KH_HASH_ROUNDS = KH_TUNE_HASH_ROUNDS;   // probes in the main LDS hash table before a key moves to the second one
-constexpr int KH_TAG_OVF = 512;             // entries of the tagged union's second table
 
 enum KhSetOp : int {
     KH_OP_UNION = 0,             // n-ary or binary union, counters combined by `mode`

@@ -1545,7 +1545,9 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     gb.wave = wave;
     gb.nwaves = nwaves;
     gb.s_scale = s_scale;
-    gb.cap = W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2;
+    // one-word keys, nothing emitted: the hash-set kernel; its slot size is a tuning choice
+    const bool hash_form = W == 1 && !emit && !getenv("KHOICE_NO_UNION_HASH");
+    gb.cap = hash_form ? kh_union_hash_capacity() : (W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2);
     bool cap_hit = false, again = false;
     {
         const int br = build_once(c, nseq, pseq.data(), plen.data(), on_device, k, 1, KH_NO_MAX, KH_KMC_DEFAULT_CS, 0, mean,
@@ -1610,7 +1612,8 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     kh_debug_set_stamps(d_stamps.as<u64>());
 #endif
     c->prof_begin(KC_UNION_TAGGED);
-    kh_launch_union_tagged(W, job, grid, k, cs, st);
+    if (hash_form) kh_launch_union_hash(job, grid, k, cs, st);
+    else kh_launch_union_tagged(W, job, grid, k, cs, st);
     c->prof_end();
     HIPCHK(hipGetLastError());
 #ifdef KH_STAMPS

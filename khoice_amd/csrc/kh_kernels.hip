@@ -1826,15 +1826,12 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_uni
     KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
     u32* pay = reinterpret_cast<u32*>(lds_raw + L.pay_off());
     u16* hstart = reinterpret_cast<u16*>(lds_raw + L.hstart_off());
-    // Carve (kh_tag_lds_bytes).  Sorting forms: the sort's carve, ginfo[64] in its lhist region, then
-    // the compact histogram hstripe[nbins][8] (8 copies per bin, copy = lane & 7).  Hash-set form
-    // (one-word keys, nothing emitted): 4096 x {key, mask} | ginfo[64] | scratch[32] | hstripe |
-    // second table [KH_TAG_OVF] x {key, mask}.
-    constexpr bool HASHED = !EMIT && W == 1;
-    u32* ginfo = reinterpret_cast<u32*>(lds_raw + (HASHED ? (size_t)65536 : L.lhist_off()));
+    // Carve (kh_tag_lds_bytes): the sort's carve, ginfo[64] in its lhist region, then the compact
+    // histogram hstripe[nbins][8] (8 copies per bin, copy = lane & 7).
+    u32* ginfo = reinterpret_cast<u32*>(lds_raw + L.lhist_off());
     u32* tab = reinterpret_cast<u32*>(lds_raw + L.tab_off());
-    u32* scratch = reinterpret_cast<u32*>(lds_raw + (HASHED ? (size_t)65536 + 256 : L.scratch_off()));
-    u32* hstripe = reinterpret_cast<u32*>(lds_raw + (HASHED ? (size_t)65536 + 256 + 128 : L.total()));   // [nbins][8]
+    u32* scratch = reinterpret_cast<u32*>(lds_raw + L.scratch_off());
+    u32* hstripe = reinterpret_cast<u32*>(lds_raw + L.total());   // [nbins][8]
     constexpr int CAPC = W == 1 ? KH_SORT_CAP_PAY_W1 : KH_SORT_CAP_PAY_W2;
     constexpr int E = (CAPC + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
     constexpr u32 NT = KH_SORT_THREADS;
@@ -1877,17 +1874,7 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_uni
             len = o1 >= o0 ? o1 - o0 : 0xffffffu;   // a corrupt index reads as "too full", never as a wrap
             if (o1 < o0) atomicOr(jb.ctl, KH_ERR_ORDER);
         }
-        if constexpr (!emit && W == 1) {
-            // hash-set form: entries {key = empty, mask = 0}, written while the index loads are in flight
-            uint4* t4 = reinterpret_cast<uint4*>(lds_raw);
-#pragma unroll
-            for (int e = 0; e < E; ++e) t4[(u32)e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
-            uint4* o4 = reinterpret_cast<uint4*>(hstripe + ((nbins * 8u + 3u) & ~3u));
-            for (u32 i = tid; i < (u32)KH_TAG_OVF; i += NT) o4[i] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
-            if (tid == 0) *reinterpret_cast<unsigned long long*>(scratch + 24) = 0ull;
-        } else {
-            distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
-        }
+        distribute_clear(reinterpret_cast<u32*>(hstart), tab + 128, scratch);
         const u32 incl = wave_scan_add(len);
         const u32 n64 = (u32)__builtin_amdgcn_readlane((int)incl, KH_WAVE - 1);
         u32 n = 0;
@@ -1964,109 +1951,9 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_uni
             }
             return ng < cs ? ng : cs;
         };
-        if constexpr (!emit && W == 1) {
-            // Nothing is written, so nothing has to be sorted — equal keys only have to MEET.  One-word
-            // keys meet in an LDS hash set: 4096 entries {key, genome mask} over the sort's key +
-            // payload + bin-table carve, home entry = the key's fine bin / 2 (keys are uniform inside
-            // the slot, so this order-preserving "hash" spreads them evenly), linear probing.  A 64-bit
-            // compare-and-swap either claims an empty entry or returns the key that lives there: one
-            // LDS round trip tells a key where its first copy is, and its genome bit is ORed in there.
-            // No counting, no scan, no scatter, no search: three phases instead of a dozen.
-            constexpr u32 T = 4096, T2 = KH_TAG_OVF;
-            constexpr u64 EMPTY = ~0ull;
-            struct alignas(16) Ent { unsigned long long key, mask; };
-            Ent* tbl = reinterpret_cast<Ent*>(lds_raw);
-            Ent* ovf = reinterpret_cast<Ent*>(hstripe + ((nbins * 8u + 3u) & ~3u));               // [T2], behind the histogram
-            unsigned long long* special = reinterpret_cast<unsigned long long*>(scratch + 24);   // mask of the key ~0
-            // (both tables were initialised while the key loads were in flight, see above)
-            // Linear probing has long clusters (max ~30 entries at this load) and the whole workgroup
-            // would wait for the one wave that walks the longest: a key gets KH_HASH_ROUNDS probes in the
-            // main table, then moves to a small second table with an independent hash.  Occupied
-            // entries stay occupied, so every copy of a key takes the same decisions as the first.
-            u32 slot[E], act = 0;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                slot[e] = binfn(kreg[e]) >> (KH_FINE_BITS - 12);
-                if ((u32)e * NT + tid < n) {
-                    if (kreg[e].lo == EMPTY) atomicOr(special, 1ull << (preg[e] & 63u));
-                    else act |= 1u << e;
-                }
-            }
-            // (two copies of the probe loop rather than a lambda: capturing `act` by reference put it on the stack)
-#define KH_PROBE_ROUNDS(TBL, TMASK, ROUNDS)                                                                           \
-            for (u32 round = 0; round < (ROUNDS) && __builtin_amdgcn_ballot_w64(act != 0); ++round) {                \
-                unsigned long long old[E];                                                                            \
-                _Pragma("unroll") for (int e = 0; e < E; ++e)                                                         \
-                    old[e] = (act & (1u << e)) ? atomicCAS(&(TBL)[slot[e]].key, EMPTY, (unsigned long long)kreg[e].lo) : 0ull; \
-                _Pragma("unroll") for (int e = 0; e < E; ++e) {                                                       \
-                    if (act & (1u << e)) {                                                                            \
-                        if (old[e] == EMPTY || old[e] == kreg[e].lo) {                                                \
-                            atomicOr(&(TBL)[slot[e]].mask, 1ull << (preg[e] & 63u));                                  \
-                            act &= ~(1u << e);                                                                        \
-                        } else {                                                                                      \
-                            slot[e] = (slot[e] + 1u) & (TMASK);                                                       \
-                        }                                                                                             \
-                    }                                                                                                 \
-                }                                                                                                     \
-            }
-            KH_PROBE_ROUNDS(tbl, T - 1u, (u32)KH_HASH_ROUNDS)
-            if (__builtin_amdgcn_ballot_w64(act != 0)) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) slot[e] = (u32)((kreg[e].lo * KH_C3) >> 40) & (T2 - 1u);
-                KH_PROBE_ROUNDS(ovf, T2 - 1u, T2)
-                // second table full of other keys (a slot of nearly all-distinct keys): on in the main
-                // table from where the first level stopped — slow, never wrong (a full table stays full)
-                if (__builtin_amdgcn_ballot_w64(act != 0)) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e)
-                        slot[e] = ((binfn(kreg[e]) >> (KH_FINE_BITS - 12)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
-                    KH_PROBE_ROUNDS(tbl, T - 1u, T)
-                    if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(lb.err, KH_ERR_CAPACITY);
-                }
-            }
-#undef KH_PROBE_ROUNDS
-            __syncthreads();
-            KH_STAMP(r, 5);
-            KH_STAMP(r, 6);
-            KH_STAMP(r, 7);
-            // every occupied entry is one distinct key of the slot
-            u64 mk[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const Ent en = tbl[(u32)e * NT + tid];
-                mk[e] = en.key != EMPTY ? en.mask : 0ull;
-            }
-            u32 gi[E];   // first group of every mask (nearly always the only one): table reads issued together
-#pragma unroll
-            for (int e = 0; e < E; ++e) gi[e] = ginfo[mk[e] ? __ffsll((unsigned long long)mk[e]) - 1 : 0];
-            u32 ones = 0;   // keys that sit in exactly one group
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                if (!mk[e]) continue;
-                const u32 ng = eval_mask(mk[e], gi[e]);
-                if (ng == 1u) ++ones;
-                else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
-            }
-            for (u32 i = tid; i < T2; i += NT) {   // keys that moved to the second table (a few per slot)
-                const Ent en = ovf[i];
-                if (en.key != EMPTY) {
-                    const u32 ng = eval_mask(en.mask, ginfo[__ffsll((unsigned long long)en.mask) - 1]);
-                    if (ng == 1u) ++ones;
-                    else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
-                }
-            }
-            if (tid == 0 && *special) {   // the one key that cannot live in the table (all bits set, k = 32 only)
-                const u64 m = *special;
-                const u32 ng = eval_mask(m, ginfo[__ffsll((unsigned long long)m) - 1]);
-                if (ng == 1u) ++ones;
-                else atomicAdd(&hstripe[(jb.abase + ng) * 8u], 1u);
-            }
-            // the across-group bin "1" would otherwise take one LDS atomic per key: per-wave sum
-            ones = wave_scan_add(ones);
-            if (lane == KH_WAVE - 1 && ones) atomicAdd(&hstripe[(jb.abase + 1u) * 8u], ones);
-            __syncthreads();
-            KH_STAMP(r, 8);
-        } else if constexpr (!emit) {
+        if constexpr (!emit) {
+            // (one-word keys normally take the hash-set form, k_union_hash below; this is the form for
+            // two-word keys, which have no 128-bit compare-and-swap to meet in a table with)
             // Nothing is written, so nothing has to be sorted: equal keys share a fine bin, every
             // key finds the first copy of itself there (find_leaders) and ORs its genome bit into
             // that copy's 64-bit mask.  The masks overlay the payload + bin-table carve (both free
@@ -2127,6 +2014,222 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_uni
             __syncthreads();
         }
     }
+    __syncthreads();
+    unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
+    for (u32 i = tid; i < nbins; i += NT) {
+        u32 v = 0;
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) v += hstripe[i * 8u + j];
+        if (v) atomicAdd(&rep[i], (unsigned long long)v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The tagged union of one-word keys when nothing is emitted (the benchmark path), as a kernel of
+// its own: LDS hash set of T entries {key, genome mask}, NT threads, 8 keys per thread, one slot
+// per workgroup (see the hash-set notes in k_union_tagged, whose other forms keep serving two-word
+// keys and emitting runs).  Templated on the geometry, which was measured both ways: <256, 2048>
+// (four workgroups per CU, 39 KB each) and <512, 4096> (two) run the headline step in the same
+// 1.70 ms — the per-slot chain of round trips does not shorten with the slot, so the throughput is
+// (keys resident in LDS per CU) / (length of that chain) either way.  <512, 4096> is what runs.
+//
+// Why a hash set: with nothing to emit, nothing has to be ordered — equal keys only have to MEET.
+// Home entry = the key's in-slot fine bin / 2 (keys are uniform inside a slot), linear probing.  A
+// 64-bit LDS compare-and-swap claims an empty entry or returns the key living there: one round
+// trip tells a key where its first copy is, and its genome bit is ORed in there.  Linear probing
+// has long clusters (max ~30 entries at this load) and the whole workgroup would wait for the one
+// wave that walks the longest: a key gets KH_HASH_ROUNDS probes in the main table, then moves to a
+// small second table with an independent hash, and from a full second table back to unbounded
+// probing of the first.  Occupied entries stay occupied, so every copy of a key takes the same
+// decisions as the first.  The all-ones key (the empty marker; k = 32 only) is carried beside.
+// ------------------------------------------------------------------------------------------
+template <u32 T> size_t kh_union_hash_lds(u32 nbins) {
+    return (size_t)T * 16 + 256 + 128 + (((size_t)nbins * 32 + 15) & ~(size_t)15) + (size_t)(T / 8) * 16;
+}
+
+template <u32 NT, u32 T>
+__global__ __launch_bounds__(NT, (T == 2048 ? 4 : 2) * (NT / 64) / 4) void k_union_hash(const KhTagJob jb, int k, u32 cs) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    constexpr int E = (int)(T / NT);
+    constexpr u32 T2 = T / 8;                 // second table
+    constexpr u32 HBITS = T == 4096 ? 12 : 11;
+    constexpr u64 EMPTY = ~0ull;
+    struct alignas(16) Ent { unsigned long long key, mask; };
+    Ent* tbl = reinterpret_cast<Ent*>(lds_raw);                                               // [T]
+    u32* ginfo = reinterpret_cast<u32*>(lds_raw + (size_t)T * 16);                           // [64]
+    u32* scratch = ginfo + 64;                                                               // [32]
+    unsigned long long* special = reinterpret_cast<unsigned long long*>(scratch + 24);       // mask of the key ~0
+    u32* hstripe = scratch + 32;                                                             // [nbins][8]
+    const u32 nbins = jb.nbins;
+    Ent* ovf = reinterpret_cast<Ent*>(hstripe + ((nbins * 8u + 3u) & ~3u));                  // [T2]
+    const u32 tid = threadIdx.x, lane = lane_id();
+    const u32 nb = jb.nb, S = jb.S, nops = jb.nops;
+    const KmerKey<1>* __restrict__ keys = reinterpret_cast<const KmerKey<1>*>(jb.keys);
+    const u32 r = blockIdx.x;
+    const u32 b = r / S, f = r - b * S;
+    // ---- operand slices of this slot: lane g of every wave describes operand g
+    const bool have = lane < nops;
+    u64 sbeg = 0;
+    u32 len = 0;
+    if (have) {
+        const u32 gb = lane * nb + b;
+        const u16* __restrict__ o = jb.off + (u64)gb * (S + 1) + f;
+        const u32 o0 = o[0], o1 = o[1];
+        sbeg = jb.bstart[gb] + o0;
+        len = o1 >= o0 ? o1 - o0 : 0xffffffu;   // a corrupt index reads as "too full", never as a wrap
+        if (o1 < o0) atomicOr(jb.ctl, KH_ERR_ORDER);
+    }
+    // tables and tables' neighbours, written while the index loads are in flight
+    for (u32 i = tid; i < (u32)KH_TAG_MAX_OPS; i += NT) ginfo[i] = jb.ginfo[i];
+    for (u32 i = tid; i < nbins * 8u; i += NT) hstripe[i] = 0;
+    {
+        uint4* t4 = reinterpret_cast<uint4*>(lds_raw);
+#pragma unroll
+        for (int e = 0; e < E; ++e) t4[(u32)e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+        uint4* o4 = reinterpret_cast<uint4*>(ovf);
+        for (u32 i = tid; i < T2; i += NT) o4[i] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+        if (tid == 0) *special = 0ull;
+    }
+    const u32 incl = wave_scan_add(len);
+    const u32 n64 = (u32)__builtin_amdgcn_readlane((int)incl, KH_WAVE - 1);
+    u32 n = 0;
+    if (n64 > T) {
+        if (tid == 0) {
+            atomicOr(jb.ctl, KH_ERR_CAPACITY);
+            atomicMax(jb.ctl + 1, n64);
+        }
+    } else {
+        n = n64;
+    }
+    const u32 soff = have ? incl - len : 0xffffffffu;
+    u64 kreg[E];
+    u32 tagp[(E + 3) / 4];
+#pragma unroll
+    for (int w = 0; w < (E + 3) / 4; ++w) tagp[w] = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        kreg[e] = EMPTY;
+        const u32 B = (u32)e * NT + (tid & ~(u32)(KH_WAVE - 1));
+        const u32 i = B + lane;
+        if (B >= n) continue;   // wave-uniform
+        const u32 g_lo = (u32)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(soff <= B))) - 1u;
+        const u32 g_hi = (u32)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(soff <= B + (KH_WAVE - 1)))) - 1u;
+        u32 ga = g_lo, my_soff;
+        u64 my_sbeg;
+        if (g_lo == g_hi) {
+            my_soff = (u32)__builtin_amdgcn_readlane((int)soff, (int)g_lo);
+            const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)sbeg, (int)g_lo);
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(sbeg >> 32), (int)g_lo);
+            my_sbeg = ((u64)hi << 32) | lo;
+        } else {   // operand boundaries inside the 64 elements: per-lane choice
+            for (u32 gg = g_lo + 1; gg <= g_hi; ++gg)
+                ga += ((u32)__builtin_amdgcn_readlane((int)soff, (int)gg) <= i) ? 1u : 0u;
+            my_soff = __shfl(soff, ga);
+            my_sbeg = __shfl(sbeg, ga);
+        }
+        if (i < n) {
+            kreg[e] = keys[my_sbeg + (i - my_soff)].lo;
+            tagp[e >> 2] |= ga << (8 * (e & 3));
+        }
+    }
+    __syncthreads();   // tables initialised
+    auto tag = [&](int e) -> u32 { return (tagp[e >> 2] >> (8 * (e & 3))) & 63u; };
+    const u32 rel0 = kh_first_bin(f, S) << (32 - KH_FINE_BITS);
+    const u32 binmul = jb.binmul, nbv = jb.nbv;
+    auto home = [=](u64 key) -> u32 {
+        const u32 frac = (u32)((u64)kh_top32(KmerKey<1>{key}, k) * (u64)nbv);
+        u32 fb = (u32)(((u64)(frac - rel0) * (u64)binmul) >> 32);
+        fb = fb < (u32)KH_FINE_BINS ? fb : (u32)KH_FINE_BINS - 1u;
+        return fb >> (KH_FINE_BITS - HBITS);
+    };
+    u32 slot[E], act = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        slot[e] = home(kreg[e]);
+        if ((u32)e * NT + tid < n) {
+            if (kreg[e] == EMPTY) atomicOr(special, 1ull << tag(e));
+            else act |= 1u << e;
+        }
+    }
+#define KH_PROBE_ROUNDS(TBL, TMASK, ROUNDS)                                                                           \
+    for (u32 round = 0; round < (ROUNDS) && __builtin_amdgcn_ballot_w64(act != 0); ++round) {                        \
+        unsigned long long old[E];                                                                                    \
+        _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                 \
+            old[e] = (act & (1u << e)) ? atomicCAS(&(TBL)[slot[e]].key, EMPTY, (unsigned long long)kreg[e]) : 0ull;   \
+        _Pragma("unroll") for (int e = 0; e < E; ++e) {                                                               \
+            if (act & (1u << e)) {                                                                                    \
+                if (old[e] == EMPTY || old[e] == kreg[e]) {                                                           \
+                    atomicOr(&(TBL)[slot[e]].mask, 1ull << tag(e));                                                   \
+                    act &= ~(1u << e);                                                                                \
+                } else {                                                                                              \
+                    slot[e] = (slot[e] + 1u) & (TMASK);                                                               \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+    KH_PROBE_ROUNDS(tbl, T - 1u, (u32)KH_HASH_ROUNDS)
+    if (__builtin_amdgcn_ballot_w64(act != 0)) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) slot[e] = (u32)((kreg[e] * KH_C3) >> 40) & (T2 - 1u);
+        KH_PROBE_ROUNDS(ovf, T2 - 1u, T2)
+        if (__builtin_amdgcn_ballot_w64(act != 0)) {   // second table full of other keys: on in the main table
+#pragma unroll
+            for (int e = 0; e < E; ++e) slot[e] = (home(kreg[e]) + (u32)KH_HASH_ROUNDS) & (T - 1u);
+            KH_PROBE_ROUNDS(tbl, T - 1u, T)
+            if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+        }
+    }
+#undef KH_PROBE_ROUNDS
+    __syncthreads();
+    // ---- every occupied entry is one distinct key of the slot: genome mask -> histogram bins
+    auto eval_mask = [&](u64 mask, u32 g) -> u32 {
+        u32 ng = 0;
+        while (true) {
+            const u32 g0 = g & 0xffu, gn = (g >> 8) & 0xffu, bin0 = g >> 16;
+            const u64 gm = (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0;
+            u32 c = (u32)__popcll(mask & gm);
+            c = c < cs ? c : cs;
+            atomicAdd(&hstripe[(bin0 + c) * 8u + (lane & 7u)], 1u);
+            mask &= ~gm;
+            ++ng;
+            if (!mask) break;
+            g = ginfo[__ffsll((unsigned long long)mask) - 1];
+        }
+        return ng < cs ? ng : cs;
+    };
+    u64 mk[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const Ent en = tbl[(u32)e * NT + tid];
+        mk[e] = en.key != EMPTY ? en.mask : 0ull;
+    }
+    u32 gi[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) gi[e] = ginfo[mk[e] ? __ffsll((unsigned long long)mk[e]) - 1 : 0];
+    u32 ones = 0;   // keys that sit in exactly one group
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (!mk[e]) continue;
+        const u32 ng = eval_mask(mk[e], gi[e]);
+        if (ng == 1u) ++ones;
+        else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
+    }
+    for (u32 i = tid; i < T2; i += NT) {   // keys that moved to the second table (a few per slot)
+        const Ent en = ovf[i];
+        if (en.key != EMPTY) {
+            const u32 ng = eval_mask(en.mask, ginfo[__ffsll((unsigned long long)en.mask) - 1]);
+            if (ng == 1u) ++ones;
+            else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
+        }
+    }
+    if (tid == 0 && *special) {   // the one key that cannot live in the tables (all bits set, k = 32 only)
+        const u64 m = *special;
+        const u32 ng = eval_mask(m, ginfo[__ffsll((unsigned long long)m) - 1]);
+        if (ng == 1u) ++ones;
+        else atomicAdd(&hstripe[(jb.abase + ng) * 8u], 1u);
+    }
+    ones = wave_scan_add(ones);
+    if (lane == KH_WAVE - 1 && ones) atomicAdd(&hstripe[(jb.abase + 1u) * 8u], ones);
     __syncthreads();
     unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
     for (u32 i = tid; i < nbins; i += NT) {
@@ -2372,9 +2475,8 @@ void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
 }
 
 size_t kh_tag_lds_bytes(int W, u32 cap, u32 nbins, bool emit) {
-    const size_t hist = ((size_t)nbins * 32 + 15) & ~(size_t)15;
-    if (W == 1 && !emit) return (size_t)65536 + 256 + 128 + hist + (size_t)KH_TAG_OVF * 16;   // hash-set form
-    return kh_sort_lds_bytes(W, cap, true) + hist;
+    (void)emit;
+    return kh_sort_lds_bytes(W, cap, true) + (((size_t)nbins * 32 + 15) & ~(size_t)15);
 }
 void kh_launch_union_tagged(int W, const KhTagJob& job, u32 grid, int k, u32 cs, hipStream_t st) {
     if (!grid) return;
@@ -2484,4 +2586,12 @@ void kh_launch_membership(int W, const void* pivot, u64 n, const KhSetView* sets
     else
         hipLaunchKernelGGL((k_membership<2>), dim3(grid), dim3(256), 0, st,
                            reinterpret_cast<const KmerKey<2>*>(pivot), n, sets, nsets, k, nwords, masks);
+}
+
+u32 kh_union_hash_capacity() { return 4096u; }
+void kh_launch_union_hash(const KhTagJob& job, u32 grid, int k, u32 cs, hipStream_t st) {
+    if (!grid) return;
+    const size_t lds = kh_union_hash_lds<4096>(job.nbins);
+    allow_lds(k_union_hash<512, 4096>, lds);
+    hipLaunchKernelGGL((k_union_hash<512, 4096>), dim3(grid), dim3(512), lds, st, job, k, cs);
 }

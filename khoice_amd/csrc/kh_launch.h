@@ -147,6 +147,9 @@ void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
                            void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
                            const KhGrid& grid, hipStream_t st);
 size_t kh_tag_lds_bytes(int W, u32 cap, u32 nbins, bool emit);
+// one-word keys, nothing emitted: the hash-set form (k_union_hash), one workgroup per slot
+u32 kh_union_hash_capacity();
+void kh_launch_union_hash(const KhTagJob& job, u32 grid, int k, u32 cs, hipStream_t st);
 void kh_launch_union_tagged(int W, const KhTagJob& job, u32 grid, int k, u32 cs, hipStream_t st);
 void kh_launch_range_bounds(int W, const KhSetView* sets, u32 nsets, u32 nranges, int k,
                             u64* bounds, u64* zero, u64 zero_words, hipStream_t st);

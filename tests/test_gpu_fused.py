@@ -165,3 +165,14 @@ def test_fused_retries_with_finer_slots(eng):
     got, _ = check(eng, seqs, group_of, 31, hist_len=64)
     assert eng.stats()["retries"] > r0
     assert int(got["across_hist"][40]) == int(got["distinct_per_seq"][0])      # every k-mer is in all forty groups
+
+
+def test_fused_fine_bin_form_for_one_word_keys(eng, monkeypatch):
+    """One-word keys normally meet in the LDS hash set (k_union_hash); the fine-bin placement +
+    leader search that two-word keys use must give the same answers for them."""
+    items = synth.species_set(3, 3, 120_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    monkeypatch.setenv("KHOICE_NO_UNION_HASH", "1")
+    for k in (13, 31, 32):
+        check(eng, seqs, group_of, k)
