@@ -568,8 +568,14 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     c->prof_begin(KC_BUCKET_PLAN);
     kh_launch_col_totals(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_tot.as<u64>(), st);
     kh_launch_exscan(d_tot.as<u64>(), d_bstart.as<u64>(), nb_total, d_scan.as<u64>(), st);
+    Tmp d_over;   // grid mode: list of the buckets above the LDS capacity
+    if (grid) {
+        TMP_ALLOC(d_over, c, 4 * ((size_t)nb_total + 1));
+        HIPCHK(hipMemsetAsync(d_over.b->p, 0, 4, st));
+    }
     kh_launch_col_offsets(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(), d_rank,
-                          d_out_base, d_work.as<KhBucketWork>(), st);
+                          d_out_base, d_work.as<KhBucketWork>(), grid ? d_over.as<u32>() : nullptr,
+                          grid ? kh_grid_bucket_capacity(W) : 0u, st);
     c->prof_end();
     if (late_alloc) {
         u64 nkeys = 0;
@@ -609,8 +615,12 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     kh_debug_set_stamps(d_stamps.as<u64>());
 #endif
     c->prof_begin(KC_BUCKET_SORT);
-    kh_launch_bucket_sort(W, d_part.b->p, d_work.as<KhBucketWork>(), nb_total, k, okeys->p,
-                          ocnt ? reinterpret_cast<u32*>(ocnt->p) : nullptr, lb, ci, cx, cs, kgrid, st);
+    if (grid)
+        kh_launch_grid_bucket(W, d_part.b->p, d_work.as<KhBucketWork>(), nb_total, k, okeys->p, d_over.as<u32>(), lb.err,
+                              kgrid, st);
+    else
+        kh_launch_bucket_sort(W, d_part.b->p, d_work.as<KhBucketWork>(), nb_total, k, okeys->p,
+                              ocnt ? reinterpret_cast<u32*>(ocnt->p) : nullptr, lb, ci, cx, cs, st);
     c->prof_end();
     HIPCHK(hipGetLastError());
 #ifdef KH_STAMPS

@@ -536,7 +536,8 @@ __global__ __launch_bounds__(64 * KH_COL_TY) void k_col_totals(const KhSeg* __re
 __global__ __launch_bounds__(64 * KH_COL_TY) void k_col_offsets(const KhSeg* __restrict__ segs, u32* __restrict__ thist,
                                                                const u64* __restrict__ bstart, const u32* __restrict__ rank,
                                                                const u64* __restrict__ seg_out_base,
-                                                               KhBucketWork* __restrict__ work) {
+                                                               KhBucketWork* __restrict__ work, u32* __restrict__ over,
+                                                               u32 over_cap) {
     __shared__ u64 part_sum[KH_COL_TY][64];
     const KhSeg sg = segs[blockIdx.y];
     const u32 b = blockIdx.x * 64 + threadIdx.x, ty = threadIdx.y;
@@ -551,8 +552,12 @@ __global__ __launch_bounds__(64 * KH_COL_TY) void k_col_offsets(const KhSeg* __r
     const u32 gb = sg.bucket_base + b;
     const u64 lo = bstart[gb];
     // pass C's work item of this bucket, at its place in the interleaved start order
-    if (ty == 0)
-        work[rank[gb]] = KhBucketWork{lo, seg_out_base[blockIdx.y], (u32)(bstart[gb + 1] - lo), sg.nb_virtual, b, gb};
+    if (ty == 0) {
+        const u64 nkeys = bstart[gb + 1] - lo;
+        work[rank[gb]] = KhBucketWork{lo, seg_out_base[blockIdx.y], (u32)nkeys, sg.nb_virtual, b, gb};
+        // grid mode: buckets above the LDS capacity go on a list for the folding kernel (over[0] = count)
+        if (over && nkeys > over_cap) over[1u + atomicAdd(&over[0], 1u)] = rank[gb];
+    }
     u64 running = lo - bstart[sg.bucket_base];
     for (u32 y = 0; y < ty; ++y) running += part_sum[y][threadIdx.x];
     for (u32 t = t0; t < t1; ++t) {
@@ -1304,7 +1309,7 @@ template <int W>
 __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_bucket_sort_rle(
     const KmerKey<W>* __restrict__ part, const KhBucketWork* __restrict__ work, u32 cap, int k,
     KmerKey<W>* __restrict__ out_keys, u32* __restrict__ out_counts, KhLookback lb, u32 ci, u32 cx,
-    u32 cs, const KhGrid grid) {
+    u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     const SortLds L{lds_raw, cap, W, false};
     KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
@@ -1360,12 +1365,6 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         KH_STAMP(q, 1);
-        if (grid.off) {
-            grid_bucket<W, E>(kreg, n, s, reinterpret_cast<u32*>(hstart), tab, scratch, tab + 128, k, seg_nb,
-                              out_keys - wk.out_base + lo, grid.off + (u64)wk.gb * (grid.S + 1), grid.S,
-                              grid.distinct + wk.gb / grid.nb, q);
-            return;
-        }
         distribute_sort<W, false, E>(kreg, preg, n, s, nullptr, reinterpret_cast<u32*>(hstart),
                                      tab + 128, tab + 128 + KH_FINE_BINS / 32, scratch, k, seg_nb, q);
         auto eval = [&](u32 h0, u32 h1) -> u32 {
@@ -1416,16 +1415,107 @@ __global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_buc
         acc = 0;
     }
     // s[0..acc) now holds distinct keys with their counters in pay[] (acc <= capp < cap)
-    if (grid.off) {
-        grid_emit<W, E>(s, acc, tab, out_keys - wk.out_base + lo, grid.off + (u64)wk.gb * (grid.S + 1), grid.S, k,
-                        seg_nb, grid.distinct + wk.gb / grid.nb);
-        return;
-    }
     auto eval = [&](u32 h0, u32 h1) -> u32 {
         const u32 c = pay[h0];
         return (c >= ci && c <= cx) ? c : 0u;
     };
     rle_emit<W, E>(s, acc, hstart, tab, eval, sink, lb, q, scratch, ci <= 1u && cx == 0xffffffffu);
+}
+
+// ------------------------------------------------------------------------------------------
+// Grid-mode pass C as a kernel of its own (buckets that fit LDS; oversize buckets are left to
+// k_bucket_sort_rle, which folds them).  Without the general path's sort, repair and look-back it
+// needs 51 KB of LDS and few enough registers for THREE workgroups per CU instead of two.
+// LDS: keys[cap] | bins[KH_FINE_BINS/2 + 1] u32 | tab[64 + 1] | lbits[128] | scratch[32]
+// ------------------------------------------------------------------------------------------
+size_t kh_grid_bucket_lds_bytes(int W, u32 cap) {
+    return (size_t)cap * 8 * W + (size_t)(KH_FINE_BINS / 2 + 4) * 4 + 80 * 4 + 128 * 4 + 32 * 4;
+}
+template <int W>
+__global__ __launch_bounds__(KH_SORT_THREADS, 6) void k_grid_bucket(const KmerKey<W>* __restrict__ part,
+                                                                  const KhBucketWork* __restrict__ work, u32 cap, int k,
+                                                                  KmerKey<W>* __restrict__ out_keys, const KhGrid grid) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw);
+    u32* bins = reinterpret_cast<u32*>(lds_raw + (size_t)cap * 8 * W);
+    u32* tab = bins + KH_FINE_BINS / 2 + 4;
+    u32* lbits = tab + 80;          // 8-byte aligned: read as 64-bit words
+    u32* scratch = lbits + 128;
+    constexpr int E = ((W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2) + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
+    const u32 tid = threadIdx.x;
+    const KhBucketWork wk = work[blockIdx.x];
+    if (wk.n > cap) return;         // on k_col_offsets' list for k_grid_oversize
+    for (u32 i = tid; i <= (u32)KH_FINE_BINS / 2; i += KH_SORT_THREADS) bins[i] = 0;
+    if (tid < 128) lbits[tid] = 0;
+    const u32 n = wk.n;
+    KmerKey<W> kreg[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        kreg[e] = key_zero<W>();
+        const u32 i = (u32)e * KH_SORT_THREADS + tid;
+        if (i < n) kreg[e] = part[wk.lo + i];
+    }
+    __syncthreads();
+    grid_bucket<W, E>(kreg, n, s, bins, tab, scratch, lbits, k, wk.nb, out_keys + wk.lo,
+                      grid.off + (u64)wk.gb * (grid.S + 1), grid.S, grid.distinct + wk.gb / grid.nb, wk.b);
+}
+
+// Buckets with more keys than fit LDS (duplicate-heavy input: tiny k, low-complexity sequence) in
+// grid mode: k_col_offsets listed them; a small grid walks the list and folds each bucket chunk by
+// chunk — [distinct keys so far | next raw chunk] -> sort -> keep the first key of every run —
+// then writes the distinct keys and the sub-range index like grid_bucket does (grid_emit: the fold
+// leaves them sorted).  Only a bucket with more DISTINCT keys than fit LDS cannot be
+// handled: KH_ERR_CAPACITY, the caller falls back to the general path.
+template <int W>
+__global__ __launch_bounds__(KH_SORT_THREADS, KH_SORT_WAVES_PER_SIMD) void k_grid_oversize(
+    const KmerKey<W>* __restrict__ part, const KhBucketWork* __restrict__ work, const u32* __restrict__ over, u32 cap,
+    int k, KmerKey<W>* __restrict__ out_keys, u32* __restrict__ err, const KhGrid grid) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    const SortLds L{lds_raw, cap, W, false};
+    KmerKey<W>* s = reinterpret_cast<KmerKey<W>*>(lds_raw + L.keys_off());
+    u16* hstart = reinterpret_cast<u16*>(lds_raw + L.hstart_off());
+    u32* tab = reinterpret_cast<u32*>(lds_raw + L.tab_off());
+    u32* scratch = reinterpret_cast<u32*>(lds_raw + L.scratch_off());
+    const u32 capp = cap;      // plain sets: only the distinct keys are kept while folding
+    constexpr int E = ((W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2) + KH_SORT_THREADS - 1) / KH_SORT_THREADS;
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const u32 count = over[0];
+    for (u32 it = blockIdx.x; it < count; it += gridDim.x) {
+        const KhBucketWork wk = work[over[1u + it]];
+        const u64 lo = wk.lo, n64 = wk.n;
+        u32 acc = 0;
+        u64 consumed = 0;
+        bool fail = false;
+        __syncthreads();   // the previous bucket's readers of s / pay / tab are done
+        while (consumed < n64) {
+            if (acc >= capp) { fail = true; break; }
+            const u64 left = n64 - consumed;
+            const u32 take = left < (u64)(capp - acc) ? (u32)left : (capp - acc);
+            const u32 m = acc + take;
+            for (u32 i = acc + tid; i < m; i += nt) {
+                s[i] = part[lo + consumed + (i - acc)];
+            }
+            __syncthreads();
+            bitonic_sort_lds<W, false>(s, nullptr, m);
+            const u32 dd = find_runs<W>(s, m, hstart, scratch);
+            for (u32 r0 = 0; r0 < dd; r0 += nt) {      // fold runs in place: slot r <- first key of run r
+                const u32 r = r0 + tid;
+                KmerKey<W> kv = key_zero<W>();
+                if (r < dd) kv = s[hstart[r]];
+                __syncthreads();
+                if (r < dd) s[r] = kv;
+                __syncthreads();
+            }
+            acc = dd;
+            consumed += take;
+        }
+        if (fail) {
+            if (tid == 0) atomicOr(err, KH_ERR_CAPACITY);
+            acc = 0;
+        }
+        grid_emit<W, E>(s, acc, tab, out_keys + lo, grid.off + (u64)wk.gb * (grid.S + 1), grid.S, k, wk.nb,
+                        grid.distinct + wk.gb / grid.nb);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2443,10 +2533,11 @@ void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* th
                        thist, tot);
 }
 void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
-                           const u32* rank, const u64* seg_out_base, KhBucketWork* work, hipStream_t st) {
+                           const u32* rank, const u64* seg_out_base, KhBucketWork* work, u32* over, u32 over_cap,
+                           hipStream_t st) {
     if (!nseg || !max_nb) return;
     hipLaunchKernelGGL(k_col_offsets, dim3((max_nb + 63) / 64, nseg), dim3(64, KH_COL_TY), 0, st, segs,
-                       thist, bstart, rank, seg_out_base, work);
+                       thist, bstart, rank, seg_out_base, work, over, over_cap);
 }
 size_t kh_exscan_tmp_words(u64 n) { return (size_t)((n + KH_SCAN_TILE - 1) / KH_SCAN_TILE) + 1; }
 void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st) {
@@ -2457,7 +2548,7 @@ void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st) 
 
 void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
                            u32 nbuckets, int k, void* out_keys, u32* out_counts, KhLookback lb,
-                           u32 ci, u32 cx, u32 cs, const KhGrid& grid, hipStream_t st) {
+                           u32 ci, u32 cx, u32 cs, hipStream_t st) {
     if (!nbuckets) return;
     const u32 cap = W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2;
     const size_t lds = kh_sort_lds_bytes(W, cap, false);
@@ -2465,12 +2556,12 @@ void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
         allow_lds(k_bucket_sort_rle<1>, lds);
         hipLaunchKernelGGL((k_bucket_sort_rle<1>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
                            reinterpret_cast<const KmerKey<1>*>(part), work, cap, k,
-                           reinterpret_cast<KmerKey<1>*>(out_keys), out_counts, lb, ci, cx, cs, grid);
+                           reinterpret_cast<KmerKey<1>*>(out_keys), out_counts, lb, ci, cx, cs);
     } else {
         allow_lds(k_bucket_sort_rle<2>, lds);
         hipLaunchKernelGGL((k_bucket_sort_rle<2>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
                            reinterpret_cast<const KmerKey<2>*>(part), work, cap, k,
-                           reinterpret_cast<KmerKey<2>*>(out_keys), out_counts, lb, ci, cx, cs, grid);
+                           reinterpret_cast<KmerKey<2>*>(out_keys), out_counts, lb, ci, cx, cs);
     }
 }
 
@@ -2594,4 +2685,36 @@ void kh_launch_union_hash(const KhTagJob& job, u32 grid, int k, u32 cs, hipStrea
     const size_t lds = kh_union_hash_lds<4096>(job.nbins);
     allow_lds(k_union_hash<512, 4096>, lds);
     hipLaunchKernelGGL((k_union_hash<512, 4096>), dim3(grid), dim3(512), lds, st, job, k, cs);
+}
+
+u32 kh_grid_bucket_capacity(int W) { return W == 1 ? KH_SORT_CAP_W1 : KH_SORT_CAP_W2; }
+void kh_launch_grid_bucket(int W, const void* part, const KhBucketWork* work, u32 nbuckets, int k, void* out_keys,
+                           const u32* over, u32* err, const KhGrid& grid, hipStream_t st) {
+    if (!nbuckets) return;
+    const u32 cap = kh_grid_bucket_capacity(W);
+    {   // the listed oversize buckets (usually none: the walkers find an empty list and leave)
+        const size_t lds2 = kh_sort_lds_bytes(W, cap, false);
+        const u32 walkers = std::min<u32>(nbuckets, 128);
+        if (W == 1) {
+            allow_lds(k_grid_oversize<1>, lds2);
+            hipLaunchKernelGGL((k_grid_oversize<1>), dim3(walkers), dim3(KH_SORT_THREADS), lds2, st,
+                               reinterpret_cast<const KmerKey<1>*>(part), work, over, cap, k,
+                               reinterpret_cast<KmerKey<1>*>(out_keys), err, grid);
+        } else {
+            allow_lds(k_grid_oversize<2>, lds2);
+            hipLaunchKernelGGL((k_grid_oversize<2>), dim3(walkers), dim3(KH_SORT_THREADS), lds2, st,
+                               reinterpret_cast<const KmerKey<2>*>(part), work, over, cap, k,
+                               reinterpret_cast<KmerKey<2>*>(out_keys), err, grid);
+        }
+    }
+    const size_t lds = kh_grid_bucket_lds_bytes(W, cap);
+    if (W == 1) {
+        allow_lds(k_grid_bucket<1>, lds);
+        hipLaunchKernelGGL((k_grid_bucket<1>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
+                           reinterpret_cast<const KmerKey<1>*>(part), work, cap, k, reinterpret_cast<KmerKey<1>*>(out_keys), grid);
+    } else {
+        allow_lds(k_grid_bucket<2>, lds);
+        hipLaunchKernelGGL((k_grid_bucket<2>), dim3(nbuckets), dim3(KH_SORT_THREADS), lds, st,
+                           reinterpret_cast<const KmerKey<2>*>(part), work, cap, k, reinterpret_cast<KmerKey<2>*>(out_keys), grid);
+    }
 }

@@ -138,14 +138,21 @@ void kh_launch_extract(int W, bool scatter, const u8* seq, const KhSeg* segs, co
                        u32 tile_pos, hipStream_t st);   // tile_pos: k-mer positions per workgroup, a multiple of 16384
 void kh_launch_col_totals(const KhSeg* segs, u32 nseg, u32 max_nb, const u32* thist, u64* tot,
                           hipStream_t st);
+// over / over_cap: grid mode only (else nullptr / 0): buckets of more than over_cap keys are listed in over[1..], over[0] = count
 void kh_launch_col_offsets(const KhSeg* segs, u32 nseg, u32 max_nb, u32* thist, const u64* bstart,
-                           const u32* rank, const u64* seg_out_base, KhBucketWork* work, hipStream_t st);
+                           const u32* rank, const u64* seg_out_base, KhBucketWork* work, u32* over, u32 over_cap,
+                           hipStream_t st);
 size_t kh_exscan_tmp_words(u64 n);
 void kh_launch_exscan(const u64* in, u64* out, u64 n, u64* tmp, hipStream_t st);   // out has n+1 entries
 void kh_launch_bucket_sort(int W, const void* part, const KhBucketWork* work,
                            u32 nbuckets, int k,
                            void* out_keys, u32* out_counts, KhLookback lb, u32 ci, u32 cx, u32 cs,
-                           const KhGrid& grid, hipStream_t st);
+                           hipStream_t st);
+// pass C in grid mode: k_grid_bucket over all buckets (three workgroups per CU; buckets above the LDS
+// capacity skipped) + k_grid_oversize over the list k_col_offsets made of those
+u32 kh_grid_bucket_capacity(int W);
+void kh_launch_grid_bucket(int W, const void* part, const KhBucketWork* work, u32 nbuckets, int k, void* out_keys,
+                           const u32* over, u32* err, const KhGrid& grid, hipStream_t st);
 size_t kh_tag_lds_bytes(int W, u32 cap, u32 nbins, bool emit);
 // one-word keys, nothing emitted: the hash-set form (k_union_hash), one workgroup per slot
 u32 kh_union_hash_capacity();
