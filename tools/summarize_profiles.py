@@ -14,7 +14,8 @@ out, tag = sys.argv[1], sys.argv[2]
 CLASS = {"k_extract<1, false>": "extract_hist", "k_extract<2, false>": "extract_hist",
          "k_extract_staged": "extract_scatter", "k_extract<1, true>": "extract_scatter",
          "k_extract<2, true>": "extract_scatter", "k_bucket_sort_rle": "bucket_sort_rle",
-         "k_setop": "setop", "k_range_bounds": "range_bounds", "k_union_tagged": "union_tagged"}
+         "k_setop": "setop", "k_range_bounds": "range_bounds", "k_union_tagged": "union_tagged",
+         "k_union_hash": "union_tagged", "k_grid_bucket": "bucket_sort_rle", "k_grid_oversize": "grid_oversize"}
 
 
 def cls(name):
