@@ -188,7 +188,8 @@ void kh_ctx::prof_collect() {
 }
 static const char* kClsNames[KC_COUNT] = {"extract_hist", "bucket_plan", "extract_scatter",
                                           "bucket_sort_rle", "range_bounds", "setop", "histogram",
-                                          "remix", "copy_in", "union_tagged"};
+                                          "remix", "copy_in", "union_tagged", "skm_scatter",
+                                          "skm_regroup", "skm_union"};
 
 // ------------------------------------------------------------------------------ ctx API
 extern "C" int kh_device_count(void) {
@@ -1502,6 +1503,214 @@ static int group_union_incremental(kh_ctx* c, const std::vector<int>& members, c
     return r;
 }
 
+// The super-k-mer form of the fused path (kh_skm.hip): bases -> 16-byte records of consecutive k-mers that
+// share their minimizer slot -> two counting-sort levels (coarse bucket, slot) -> one LDS hash set per
+// slot.  Takes what the key-array form below takes when k is in [KH_SKM_MIN_K, KH_SKM_MAX_K], nothing is
+// emitted and the batch fits one slot grid; *done == false: not applicable, or a region overflowed
+// (low-complexity input, far more records than estimated) — the caller goes on to the key-array form.
+static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
+                    const int* group_of, int ngroups, int k, u32 cs, uint64_t* within_hist,
+                    uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, bool* done) {
+    *done = false;
+    if (k < KH_SKM_MIN_K || k > KH_SKM_MAX_K || getenv("KHOICE_NO_SKM")) return KH_OK;
+    if (nseq > KH_TAG_MAX_OPS || ngroups > KH_TAG_MAX_OPS) return KH_OK;
+    std::vector<int> gsize(ngroups, 0), gstart(ngroups + 1, 0), perm(nseq);
+    for (int i = 0; i < nseq; ++i) gsize[group_of[i]]++;
+    u32 nbins = 0;
+    std::vector<u32> bin0(ngroups);
+    for (int g = 0; g < ngroups; ++g) {
+        if (!gsize[g]) return kh_fail(KH_E_ARG, "group %d has no sequences", g);
+        gstart[g + 1] = gstart[g] + gsize[g];
+        bin0[g] = nbins;
+        nbins += (u32)gsize[g] + 1;
+    }
+    const u32 abase = nbins;
+    nbins += (u32)ngroups + 1;
+    if (nbins > (u32)KH_TAG_MAX_BINS) return KH_OK;
+    {
+        std::vector<int> at(gstart.begin(), gstart.end() - 1);
+        for (int i = 0; i < nseq; ++i) perm[at[group_of[i]]++] = i;
+    }
+    // ---- geometry: minimizer length, slots, regions
+    const int m15w = k - 15 + 1;                                   // m-mers per k-mer with m = 15
+    const int m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;   // m = 16 when that makes w a power of two
+    const u32 w = (u32)(k - m + 1);
+    const u32 nmax = (u32)std::min(31, 55 - k);
+    u64 total_pos = 0, bases = 0, seq_bytes = 0;
+    for (int i = 0; i < nseq; ++i) {
+        total_pos += lens[i] >= (u64)k ? lens[i] - k + 1 : 0;
+        bases += lens[i];
+    }
+    if (!total_pos) return KH_OK;
+    u32 mean = 2900;
+    if (const char* e = getenv("KHOICE_SKM_MEAN")) mean = std::max<u32>(64, (u32)strtoul(e, nullptr, 10));
+    const u64 nslots64 = std::max<u64>(1, (total_pos + mean - 1) / mean);
+    if (nslots64 > (u64)KH_SKM_MAX_COARSE * KH_SKM_MAX_FINE) return KH_OK;
+    const u32 nslots = (u32)nslots64;
+    const u32 S = std::max<u32>(1, (nslots + KH_SKM_MAX_COARSE - 1) / KH_SKM_MAX_COARSE);
+    const u32 nb1 = (nslots + S - 1) / S;
+    // records: a run of k-mers with one minimizer is w/2 + 1/2 long on average and is cut at every
+    // 32-position thread boundary and at nmax
+    const double per_kmer = 1.0 / 32.0 + 2.0 / (double)(w + 1) + 1.0 / (double)nmax;
+    const double recs = (double)total_pos * per_kmer;
+    double slack1 = 1.25, slack2 = 1.7;
+    if (const char* e = getenv("KHOICE_SKM_SLACK")) slack1 = slack2 = std::max(0.01, atof(e));   // below 1: tests of the overflow fall-back
+    const u64 cap1_64 = ((u64)(recs / nb1 * slack1) + 2048 + 63) & ~63ull;
+    const u64 cap2_64 = ((u64)(recs / nslots * slack2) + 96 + 15) & ~15ull;
+    if (cap2_64 > KH_SKM_MAX_CAP2 || cap1_64 > 0x7fffffffull) return KH_OK;
+    const u32 cap1 = (u32)cap1_64, cap2 = (u32)cap2_64;
+    const size_t reg1_bytes = 16 * (size_t)nb1 * cap1, reg2_bytes = 16 * (size_t)nslots * cap2;
+    HIPCHK(hipSetDevice(c->dev));
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+            reg1_bytes + reg2_bytes + bases + (64u << 20) > free_b + c->pool.cached_bytes)
+            return KH_OK;   // the key-range waves of the key-array form handle what does not fit
+    }
+    hipStream_t st = c->st;
+
+    // ---- segments and tiles (operands in group-major order: the genomes of a group are consecutive mask bits)
+    u32 tile_pos = KH_TILE;
+    {
+        const u64 want_tiles = 8ull * (u64)std::max(1, c->cus);
+        while (tile_pos > (u32)KH_SUBTILE && (total_pos + tile_pos - 1) / tile_pos < want_tiles) tile_pos >>= 1;
+    }
+    std::vector<KhSeg> segs(nseq);
+    std::vector<u64> pack_off(nseq);
+    std::vector<KhTile> tiles;
+    for (int i = 0; i < nseq; ++i) {
+        KhSeg& sg = segs[i];
+        memset(&sg, 0, sizeof sg);
+        const u64 len = lens[perm[i]];
+        pack_off[i] = seq_bytes;
+        sg.len = len;
+        sg.npos = len >= (u64)k ? len - k + 1 : 0;
+        sg.ntiles = (u32)((sg.npos + tile_pos - 1) / tile_pos);
+        sg.tile_base = (u32)tiles.size();
+        for (u32 t = 0; t < sg.ntiles; ++t) tiles.push_back(KhTile{(u32)i, t});
+        seq_bytes += (len + 15) & ~15ull;
+    }
+    seq_bytes += 256;
+    const u32 ntiles = (u32)tiles.size();
+    const u32 reps = std::min<u32>(256, std::max<u32>(1, nslots));
+    const size_t hist_words = (size_t)reps * nbins;
+    // workspace: [hist][ctl: 8 u32][inst: nseq u64][dup: 64 u64][cur1: nb1 u32][cur2: nslots u32] (zeroed) [ginfo: 64 u32]
+    const size_t off_ctl = 8 * hist_words, off_inst = off_ctl + 32, off_dup = off_inst + 8 * (size_t)nseq,
+                 off_cur1 = off_dup + 8 * 64, off_cur2 = off_cur1 + 4 * (size_t)((nb1 + 3) & ~3u),
+                 off_ginfo = off_cur2 + 4 * (size_t)((nslots + 3) & ~3u), ws_bytes = off_ginfo + 256;
+    Tmp d_seq, d_segs, d_tiles, d_ws, d_reg1, d_reg2;
+    bool need_pack = false;
+    for (int i = 0; i < nseq; ++i)
+        if (!(on_device && (reinterpret_cast<uintptr_t>(seqs[perm[i]]) & 15) == 0)) need_pack = true;
+    TMP_ALLOC(d_seq, c, need_pack ? seq_bytes : 256);
+    TMP_ALLOC(d_segs, c, sizeof(KhSeg) * nseq);
+    TMP_ALLOC(d_tiles, c, sizeof(KhTile) * std::max<u32>(1, ntiles));
+    TMP_ALLOC(d_ws, c, ws_bytes);
+    TMP_ALLOC(d_reg1, c, reg1_bytes);
+    TMP_ALLOC(d_reg2, c, reg2_bytes);
+    struct PinG { kh_ctx* c; void* p = nullptr; size_t n = 0; ~PinG() { if (p) c->pin_release(p, n); } } pin{c};
+    // pinned staging: [segs][tiles][ginfo] up, [hist .. dup] down
+    const size_t up_bytes = sizeof(KhSeg) * nseq + sizeof(KhTile) * (size_t)ntiles + 256;
+    const size_t down_bytes = off_cur1;
+    pin.p = c->pin_alloc(up_bytes + down_bytes + 64, &pin.n);
+    if (!pin.p) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
+    u8* h_up = static_cast<u8*>(pin.p);
+    u8* h_down = h_up + ((up_bytes + 63) & ~(size_t)63);
+    c->prof_begin(KC_COPY_IN);
+    for (int i = 0; i < nseq; ++i) {
+        const uint8_t* src = seqs[perm[i]];
+        if (on_device && (reinterpret_cast<uintptr_t>(src) & 15) == 0) { segs[i].seq = src; continue; }
+        segs[i].seq = d_seq.as<u8>() + pack_off[i];
+        if (!segs[i].len) continue;
+        HIPCHK(hipMemcpyAsync(d_seq.as<u8>() + pack_off[i], src, segs[i].len,
+                              on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    }
+    KhSeg* h_segs = reinterpret_cast<KhSeg*>(h_up);
+    KhTile* h_tiles = reinterpret_cast<KhTile*>(h_up + sizeof(KhSeg) * nseq);
+    u32* h_ginfo = reinterpret_cast<u32*>(h_up + sizeof(KhSeg) * nseq + sizeof(KhTile) * (size_t)ntiles);
+    memcpy(h_segs, segs.data(), sizeof(KhSeg) * nseq);
+    if (ntiles) memcpy(h_tiles, tiles.data(), sizeof(KhTile) * (size_t)ntiles);
+    memset(h_ginfo, 0, 256);
+    for (int g = 0; g < ngroups; ++g)
+        for (int j = 0; j < gsize[g]; ++j)
+            h_ginfo[gstart[g] + j] = (u32)gstart[g] | ((u32)gsize[g] << 8) | (bin0[g] << 16);
+    HIPCHK(hipMemcpyAsync(d_segs.b->p, h_segs, sizeof(KhSeg) * nseq, hipMemcpyHostToDevice, st));
+    if (ntiles) HIPCHK(hipMemcpyAsync(d_tiles.b->p, h_tiles, sizeof(KhTile) * (size_t)ntiles, hipMemcpyHostToDevice, st));
+    u8* wsp = d_ws.as<u8>();
+    HIPCHK(hipMemsetAsync(wsp, 0, off_ginfo, st));
+    HIPCHK(hipMemcpyAsync(wsp + off_ginfo, h_ginfo, 256, hipMemcpyHostToDevice, st));
+    c->prof_end();
+
+    KhSkmJob job;
+    job.segs = d_segs.as<KhSeg>();
+    job.tiles = d_tiles.as<KhTile>();
+    job.reg1 = d_reg1.as<uint4>();
+    job.reg2 = d_reg2.as<uint4>();
+    job.cur1 = reinterpret_cast<u32*>(wsp + off_cur1);
+    job.cur2 = reinterpret_cast<u32*>(wsp + off_cur2);
+    job.inst = reinterpret_cast<unsigned long long*>(wsp + off_inst);
+    job.dup = reinterpret_cast<unsigned long long*>(wsp + off_dup);
+    job.ginfo = reinterpret_cast<const u32*>(wsp + off_ginfo);
+    job.hist = reinterpret_cast<unsigned long long*>(wsp);
+    job.ctl = reinterpret_cast<u32*>(wsp + off_ctl);
+    job.tile_pos = tile_pos;
+    job.k = k; job.m = m; job.w = w; job.nmax = nmax;
+    job.nslots = nslots; job.S = S; job.nb1 = nb1; job.cap1 = cap1; job.cap2 = cap2;
+    job.nbins = nbins; job.abase = abase; job.reps = reps; job.nops = (u32)nseq;
+    c->prof_begin(KC_SKM_SCATTER);
+    kh_launch_skm_scatter(job, ntiles, st);
+    c->prof_end();
+    c->prof_begin(KC_SKM_REGROUP);
+    kh_launch_skm_regroup(job, st);
+    c->prof_end();
+    c->prof_begin(KC_SKM_UNION);
+    kh_launch_skm_union(job, cs, st);
+    c->prof_end();
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_down, wsp, down_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const u64* h_hist = reinterpret_cast<const u64*>(h_down);
+    const u32* h_ctl = reinterpret_cast<const u32*>(h_down + off_ctl);
+    const u64* h_inst = reinterpret_cast<const u64*>(h_down + off_inst);
+    const u64* h_dup = reinterpret_cast<const u64*>(h_down + off_dup);
+    if (h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER)) {
+        c->stat.retries++;
+        return KH_OK;   // a region or a slot overflowed: the key-array form takes over
+    }
+    c->stat.bases += bases;
+    c->stat.builds += nseq;
+    u64 inst = 0, dsum = 0;
+    for (int i = 0; i < nseq; ++i) {
+        const u64 d = h_inst[i] - h_dup[i];
+        inst += h_inst[i];
+        dsum += d;
+        if (distinct_per_seq) distinct_per_seq[perm[i]] = d;
+    }
+    c->stat.kmers += inst;
+    c->stat.distinct += dsum;
+    c->stat.setops++;
+    c->stat.setop_in += dsum;
+    std::vector<u64> bins(nbins, 0);
+    for (u32 r = 0; r < reps; ++r)
+        for (u32 b = 0; b < nbins; ++b) bins[b] += h_hist[(size_t)r * nbins + b];
+    if (within_hist) {
+        memset(within_hist, 0, 8 * (size_t)ngroups * hist_len);
+        for (int g = 0; g < ngroups; ++g)
+            for (int cnt = 1; cnt <= gsize[g]; ++cnt)
+                within_hist[(size_t)g * hist_len + std::min<u32>((u32)cnt, hist_len - 1)] += bins[bin0[g] + cnt];
+    }
+    u64 across_n = 0;
+    for (int cnt = 1; cnt <= ngroups; ++cnt) across_n += bins[abase + cnt];
+    c->stat.setop_out += across_n;
+    if (across_hist) {
+        memset(across_hist, 0, 8 * (size_t)hist_len);
+        for (int cnt = 1; cnt <= ngroups; ++cnt)
+            across_hist[std::min<u32>((u32)cnt, hist_len - 1)] += bins[abase + cnt];
+    }
+    *done = true;
+    return KH_OK;
+}
+
 // The fused form of steps 1-8 (no per-genome / per-group database is handed out): ONE batched build
 // in grid mode, ONE tagged union over all genomes, ONE host synchronisation.  *done == false on
 // return means "not applicable or a slot overflowed": the caller takes the general path.
@@ -1750,6 +1959,11 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
             for (int g = 0; g < ngroups; ++g) all_bases += gbases[g];
             bool done = false;
             double scale = 0.0;
+            if (!across_set) {   // histograms and distinct counts only: the super-k-mer form
+                KHCHK(exp1_skm(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, within_hist, across_hist,
+                               hist_len, distinct_per_seq, &done));
+                if (done) return KH_OK;
+            }
             KHCHK(exp1_fused(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, within_hist, across_hist,
                              hist_len, distinct_per_seq, across_set, &done, waves_for(all_bases), 1.0, &scale));
             if (done) return KH_OK;

@@ -117,6 +117,42 @@ struct KhTagJob {
     unsigned long long* out_n;  // number of records written
 };
 
+// ---- super-k-mer form of the fused path (kh_skm.hip): records of n consecutive k-mers that share their
+// minimizer slot, partitioned in two levels (coarse bucket, then slot = coarse * S + fine), then one LDS
+// hash set per slot.  A record is 16 bytes: bits [0, 2(n+k-1)) the bases (base j at bits 2j, A0 C1 G2 T3),
+// bits 108..116 the fine index of its slot, 117..122 the genome (operand) number, 123..127 n.
+constexpr u32 KH_SKM_STAGE = 2048;        // records counting-sorted in LDS per flush
+constexpr u32 KH_SKM_MAX_COARSE = 256;    // coarse buckets (LDS counters of the scatter)
+constexpr u32 KH_SKM_MAX_FINE = 512;      // slots per coarse bucket (9 bits in the record)
+constexpr u32 KH_SKM_MAX_CAP2 = 2048;     // records of one slot (the union reads four per thread)
+constexpr u32 KH_SKM_MAX_SLOT_KMERS = 16384;   // k-mer instances of one slot the union can index
+constexpr int KH_SKM_MIN_K = 20, KH_SKM_MAX_K = 32;
+struct KhSkmJob {
+    const KhSeg* segs;
+    const KhTile* tiles;
+    uint4* reg1;                    // [nb1][cap1] records by coarse bucket
+    uint4* reg2;                    // [nslots][cap2] records by slot
+    u32* cur1;                      // [nb1] zeroed
+    u32* cur2;                      // [nslots] zeroed
+    unsigned long long* inst;       // [nops] valid k-mer instances per genome
+    unsigned long long* dup;        // [64] instances whose (k-mer, genome) pair was seen before
+    const u32* ginfo;               // as KhTagJob
+    unsigned long long* hist;       // [reps][nbins]
+    u32* ctl;                       // [0] error bits, [1] fullest slot seen
+    u32 tile_pos;
+    int k, m;                       // m-mer length of the minimizer (<= 16)
+    u32 w;                          // m-mers per k-mer: k - m + 1
+    u32 nmax;                       // k-mers per record at most
+    u32 nslots, S, nb1, cap1, cap2;
+    u32 nbins, abase, reps, nops;
+};
+size_t kh_skm_scatter_lds_bytes(u32 nb1);
+size_t kh_skm_regroup_lds_bytes(u32 S);
+size_t kh_skm_union_lds_bytes(u32 nbins);
+void kh_launch_skm_scatter(const KhSkmJob& job, u32 ntiles, hipStream_t st);
+void kh_launch_skm_regroup(const KhSkmJob& job, hipStream_t st);
+void kh_launch_skm_union(const KhSkmJob& job, u32 cs, hipStream_t st);
+
 struct KhLookback {      // workspace of one ordered single-pass launch
     u64* desc;           // [nparts] tile descriptors, zeroed before launch
     u32* ticket;         // zeroed before launch

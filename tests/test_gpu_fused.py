@@ -25,10 +25,13 @@ def eng():
 
 def check(eng, seqs, group_of, k, cs=5000, hist_len=5001, expect_fused=True):
     want = CO.exp1(seqs, group_of, k, cs=cs, hist_len=hist_len)
-    before = eng.stats()["kernels"]["union_tagged"]["launches"]
+    def fused_launches():   # either form of the fused path: key arrays (union_tagged) or super-k-mers (skm_union)
+        kern = eng.stats()["kernels"]
+        return kern["union_tagged"]["launches"] + kern["skm_union"]["launches"]
+    before = fused_launches()
     eng.profile(True)
     got = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len)
-    after = eng.stats()["kernels"]["union_tagged"]["launches"]
+    after = fused_launches()
     eng.profile(False)
     if expect_fused:
         assert after > before, "the fused path did not run"      # one launch per batch of groups and key-range wave
