@@ -41,20 +41,28 @@ __device__ __forceinline__ u32 wave_scan_max(u32 v) {
 
 constexpr int KH_HALO = 96;                                   // k-1 <= 63 bases + two words of slack for the funnel shifts
 
-// 16 ASCII bases -> 16 two-bit codes + 16 "not ACGTacgt" flags.
+// 16 ASCII bases -> 16 two-bit codes + 16 "not ACGTacgt" flags, four bytes at a time (SWAR):
+//   code = ((c >> 1) ^ (c >> 2)) & 3 maps A C G T (either case) to 0 1 2 3; the letter that code stands for is
+//   0x41 + {0, 2, 6, 0x13}[code], and a byte is a base iff its case-folded value equals that letter.
+// The two multiplies gather the four 2-bit codes / the four flags of a word into its top byte / nibble
+// (the partial products land on distinct bits: no carries).
+__device__ __forceinline__ void decode4(const u32 x, u32& codes8, u32& bad4) {
+    const u32 t = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    codes8 = (t * 0x01041040u) >> 24;
+    const u32 b0 = t & 0x01010101u, b1 = (t >> 1) & 0x01010101u, both = b0 & b1;
+    const u32 letter = 0x41414141u + ((b0 | b1) << 1) + ((b1 & ~b0) << 2) + both + (both << 4);
+    const u32 z = (x & 0xDFDFDFDFu) ^ letter;
+    const u32 nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;   // bit 7 of every byte that differs
+    bad4 = ((nz >> 7) * 0x10204080u) >> 28;
+}
 __device__ __forceinline__ void decode16(const uint4 v, u32& codes, u32& bad) {
-    const u32 w[4] = {v.x, v.y, v.z, v.w};
-    codes = 0;
-    bad = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const u32 c = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
-        const u32 up = c & 0xdfu;                              // fold case
-        const u32 code = ((c >> 1) ^ (c >> 2)) & 3u;            // A0 C1 G2 T3
-        const bool ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
-        codes |= code << (2 * i);
-        bad |= (ok ? 0u : 1u) << i;
-    }
+    u32 c0, c1, c2, c3, f0, f1, f2, f3;
+    decode4(v.x, c0, f0);
+    decode4(v.y, c1, f1);
+    decode4(v.z, c2, f2);
+    decode4(v.w, c3, f3);
+    codes = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+    bad = f0 | (f1 << 4) | (f2 << 8) | (f3 << 12);
 }
 
 // Bases [p0, p0 + 16 * nwords) of a sequence -> LDS: code[w] = 16 two-bit codes (base j of the

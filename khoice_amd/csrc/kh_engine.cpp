@@ -349,6 +349,7 @@ extern "C" int kh_set_counts(kh_ctx* c, const kh_set* in, uint32_t value, kh_set
 
 #ifdef KH_STAMPS
 void kh_debug_set_stamps(u64* p);
+void kh_debug_set_stamps_skm(u64* p);
 // diagnostic build: average shader-clock deltas between phase stamps over all workgroups
 static void report_stamps(kh_ctx* c, const char* what, DevBuf* sb, u64 nparts) {
     std::vector<u64> h(nparts * 16);
@@ -376,6 +377,19 @@ static void report_stamps(kh_ctx* c, const char* what, DevBuf* sb, u64 nparts) {
     fprintf(stderr, "[stamps] %s parts=%llu span=%.0f cyc | load %.0f count %.0f scan %.0f scatter %.0f insert %.0f walk1 %.0f lookback %.0f walk2 %.0f\n",
             what, (unsigned long long)cnt, (double)(tmax - tmin), sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt,
             sum[5] / cnt, sum[6] / cnt, sum[7] / cnt, sum[8] / cnt);
+    {   // every stamp as an offset from stamp 0 (order-free: stamps 9..15 may sit anywhere)
+        std::string line;
+        for (int i = 1; i < 16; ++i) {
+            double s2 = 0; u64 c2 = 0;
+            for (u64 q = 0; q < nparts; ++q) {
+                const u64* t = &h[q * 16];
+                if (!t[0] || !t[i]) continue;
+                ++c2; s2 += (double)((long long)(t[i] - t[0]));
+            }
+            if (c2) { char b[64]; snprintf(b, sizeof b, " t%d=%.0f(n=%llu)", i, s2 / c2, (unsigned long long)c2); line += b; }
+        }
+        fprintf(stderr, "[stamps] %s offsets from t0:%s\n", what, line.c_str());
+    }
 }
 #endif
 
@@ -1536,6 +1550,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     const int m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;   // m = 16 when that makes w a power of two
     const u32 w = (u32)(k - m + 1);
     const u32 nmax = (u32)std::min(31, 55 - k);
+    if (!kh_skm_supports_w(w)) return KH_OK;
     u64 total_pos = 0, bases = 0, seq_bytes = 0;
     for (int i = 0; i < nseq; ++i) {
         total_pos += lens[i] >= (u64)k ? lens[i] - k + 1 : 0;
@@ -1596,7 +1611,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     const size_t hist_words = (size_t)reps * nbins;
     // workspace: [hist][ctl: 8 u32][inst: nseq u64][dup: 64 u64][cur1: nb1 u32][cur2: nslots u32] (zeroed) [ginfo: 64 u32]
     const size_t off_ctl = 8 * hist_words, off_inst = off_ctl + 32, off_dup = off_inst + 8 * (size_t)nseq,
-                 off_cur1 = off_dup + 8 * 64, off_cur2 = off_cur1 + 4 * (size_t)((nb1 + 3) & ~3u),
+                 off_cur1 = off_dup + 8 * 64, off_cur2 = off_cur1 + 4 * (size_t)KH_SKM_CUR1_STRIDE * nb1,
                  off_ginfo = off_cur2 + 4 * (size_t)((nslots + 3) & ~3u), ws_bytes = off_ginfo + 256;
     Tmp d_seq, d_segs, d_tiles, d_ws, d_reg1, d_reg2;
     bool need_pack = false;
@@ -1657,16 +1672,49 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     job.k = k; job.m = m; job.w = w; job.nmax = nmax;
     job.nslots = nslots; job.S = S; job.nb1 = nb1; job.cap1 = cap1; job.cap2 = cap2;
     job.nbins = nbins; job.abase = abase; job.reps = reps; job.nops = (u32)nseq;
+#ifdef KH_STAMPS
+    Tmp d_stamps;
+    const u64 nst = std::max<u64>(ntiles, nslots);
+    TMP_ALLOC(d_stamps, c, 128 * nst);
+    HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * nst, st));
+    kh_debug_set_stamps_skm(d_stamps.as<u64>());
+#endif
     c->prof_begin(KC_SKM_SCATTER);
     kh_launch_skm_scatter(job, ntiles, st);
     c->prof_end();
+#ifdef KH_STAMPS
+    report_stamps(c, "skm_scatter (second sub-tile: codes / hashes / minima / slots+count / - / append / barrier / -)", d_stamps.b, ntiles);
+    HIPCHK(hipMemsetAsync(d_stamps.b->p, 0, 128 * nst, st));
+    kh_debug_set_stamps_skm(nullptr);
+#endif
     c->prof_begin(KC_SKM_REGROUP);
     kh_launch_skm_regroup(job, st);
     c->prof_end();
+#ifdef KH_STAMPS
+    kh_debug_set_stamps_skm(d_stamps.as<u64>());
+#endif
     c->prof_begin(KC_SKM_UNION);
     kh_launch_skm_union(job, cs, st);
     c->prof_end();
     HIPCHK(hipGetLastError());
+#ifdef KH_STAMPS
+    report_stamps(c, "skm_union (scan barrier / owner / expand / insert / barrier / read-out / barrier / flush)", d_stamps.b, nslots);
+    kh_debug_set_stamps_skm(nullptr);
+#endif
+    if (getenv("KHOICE_SKM_DEBUG")) {   // diagnostics: how full the regions are
+        std::vector<u32> h1(nb1), h2(nslots);
+        HIPCHK(hipMemcpy2DAsync(h1.data(), 4, job.cur1, 4 * (size_t)KH_SKM_CUR1_STRIDE, 4, nb1, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h2.data(), job.cur2, 4 * (size_t)nslots, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        u64 t1 = 0, t2 = 0;
+        u32 m1 = 0, m2 = 0;
+        for (u32 v : h1) { t1 += v; m1 = std::max(m1, v); }
+        for (u32 v : h2) { t2 += v; m2 = std::max(m2, v); }
+        fprintf(stderr, "[skm] k=%d m=%d w=%u nmax=%u positions=%llu records=%llu (%.2f k-mers each) nb1=%u S=%u nslots=%u | "
+                        "coarse: mean %.0f max %u cap %u | slot: mean %.1f max %u cap %u | tiles %u x %u\n",
+                k, m, w, nmax, (unsigned long long)total_pos, (unsigned long long)t1, (double)total_pos / std::max<u64>(1, t1),
+                nb1, S, nslots, (double)t1 / nb1, m1, cap1, (double)t2 / nslots, m2, cap2, ntiles, tile_pos);
+    }
     HIPCHK(hipMemcpyAsync(h_down, wsp, down_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const u64* h_hist = reinterpret_cast<const u64*>(h_down);

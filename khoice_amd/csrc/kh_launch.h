@@ -121,18 +121,23 @@ struct KhTagJob {
 // minimizer slot, partitioned in two levels (coarse bucket, then slot = coarse * S + fine), then one LDS
 // hash set per slot.  A record is 16 bytes: bits [0, 2(n+k-1)) the bases (base j at bits 2j, A0 C1 G2 T3),
 // bits 108..116 the fine index of its slot, 117..122 the genome (operand) number, 123..127 n.
-constexpr u32 KH_SKM_STAGE = 2048;        // records counting-sorted in LDS per flush
+constexpr u32 KH_SKM_STAGE = 1536;        // records counting-sorted in LDS per flush of the scatter
 constexpr u32 KH_SKM_MAX_COARSE = 256;    // coarse buckets (LDS counters of the scatter)
 constexpr u32 KH_SKM_MAX_FINE = 512;      // slots per coarse bucket (9 bits in the record)
 constexpr u32 KH_SKM_MAX_CAP2 = 2048;     // records of one slot (the union reads four per thread)
-constexpr u32 KH_SKM_MAX_SLOT_KMERS = 16384;   // k-mer instances of one slot the union can index
 constexpr int KH_SKM_MIN_K = 20, KH_SKM_MAX_K = 32;
+#ifndef KH_TUNE_SKM_CUR1_STRIDE
+#define KH_TUNE_SKM_CUR1_STRIDE 1088
+#endif
+// u32 words between the cursors of two coarse buckets: every flush of every workgroup adds to all of them,
+// so they are kept on different memory channels (4352 bytes apart) instead of sixteen to a cache line
+constexpr u32 KH_SKM_CUR1_STRIDE = KH_TUNE_SKM_CUR1_STRIDE;
 struct KhSkmJob {
     const KhSeg* segs;
     const KhTile* tiles;
     uint4* reg1;                    // [nb1][cap1] records by coarse bucket
     uint4* reg2;                    // [nslots][cap2] records by slot
-    u32* cur1;                      // [nb1] zeroed
+    u32* cur1;                      // [nb1 * KH_SKM_CUR1_STRIDE] zeroed: cursor of bucket b at b * KH_SKM_CUR1_STRIDE
     u32* cur2;                      // [nslots] zeroed
     unsigned long long* inst;       // [nops] valid k-mer instances per genome
     unsigned long long* dup;        // [64] instances whose (k-mer, genome) pair was seen before
@@ -146,6 +151,7 @@ struct KhSkmJob {
     u32 nslots, S, nb1, cap1, cap2;
     u32 nbins, abase, reps, nops;
 };
+bool kh_skm_supports_w(u32 w);   // m-mers per k-mer the scatter kernel is instantiated for
 size_t kh_skm_scatter_lds_bytes(u32 nb1);
 size_t kh_skm_regroup_lds_bytes(u32 S);
 size_t kh_skm_union_lds_bytes(u32 nbins);

@@ -12,8 +12,9 @@
 //                   their minimizer, so a run of n of them travels as ONE 16-byte record (n + k - 1 bases
 //                   at two bits, genome tag, n): ~2 bytes per k-mer instead of 8.  Records are counting-
 //                   sorted by coarse bucket in LDS and flushed as runs (one global atomic per run).
-//   k_skm_regroup   one coarse bucket at a time, 2048 records per workgroup: the same LDS counting sort
-//                   by fine slot -> every slot of the key space is one contiguous record range.
+//   k_skm_regroup   one workgroup per coarse bucket, 8192 records per round: the same LDS counting sort by
+//                   fine slot (cursors in LDS: the workgroup owns its slots) -> every slot of the key space
+//                   is one contiguous record range.
 //   k_skm_union     one workgroup per slot: records -> k-mers (balanced: a thread takes 8 consecutive
 //                   k-mer indices of the slot, whatever records they fall in) -> canonical key -> LDS hash
 //                   set {key, genome mask} -> popcount per group / number of groups -> histogram bins.
@@ -27,26 +28,46 @@
 #include "kh_device.h"
 #include "kh_launch.h"
 
+// Diagnostic build only (-DKH_STAMPS): thread 0 of a workgroup stores the shader clock at phase boundaries.
+#ifdef KH_STAMPS
+__device__ u64* g_skm_stamps = nullptr;
+void kh_debug_set_stamps_skm(u64* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_skm_stamps), &p, sizeof p); }
+#define SKM_STAMP(idx)                                                                     \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (threadIdx.x == 0 && g_skm_stamps)                                              \
+            g_skm_stamps[((u64)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (idx)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+#else
+#define SKM_STAMP(idx) do {} while (0)
+#endif
+
+#ifndef KH_TUNE_SKM_OVF_SERIAL
+#define KH_TUNE_SKM_OVF_SERIAL 0
+#endif
+#ifndef KH_TUNE_SKM_SCATTER_WAVES
+#define KH_TUNE_SKM_SCATTER_WAVES 3   // waves per SIMD the scatter is compiled for (workgroups of 4 waves per CU)
+#endif
+
 namespace {
 
-constexpr u32 SKM_NT = 256;                    // threads of a scatter / regroup workgroup
+constexpr u32 SKM_NT = 256;                    // threads of a scatter workgroup
 constexpr u32 SKM_PPT = 32;                    // k-mer start positions per thread and sub-tile
 constexpr u32 SKM_SUB = SKM_NT * SKM_PPT;      // 8192 positions per sub-tile
 constexpr u32 SKM_CW = (SKM_SUB + KH_HALO) / 16;
-constexpr u32 SKM_CAP = KH_SKM_STAGE;          // records staged in LDS per flush
-constexpr u32 SKM_ROW = SKM_NT + 1;            // row stride of the transposed per-position arrays
-constexpr u32 SKM_RPT = SKM_CAP / SKM_NT;      // staged records per thread in a flush
-constexpr int SKM_MAXL = 16;                   // largest power-of-two window of m-mers (k <= 32, m >= 15: w <= 18)
+constexpr u32 SKM_CAP = KH_SKM_STAGE;          // records staged in LDS per flush of the scatter
+constexpr int SKM_WMIN = 5, SKM_WMAX = 18;     // m-mers per k-mer the scatter is instantiated for
+constexpr u32 SKM_RG_NT = 1024;                // regroup: one workgroup per coarse bucket
+constexpr u32 SKM_RG_CAP = 8192;               // records per round of the regroup
 
 __device__ __forceinline__ u32 revpairs32(u32 x) {
     x = __builtin_bitreverse32(x);
     return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
 }
 __device__ __forceinline__ u32 mmer_hash(u32 canon) {   // order of the m-mers: a bijection on 32 bits
-    u32 h = canon * 0x9E3779B1u;
+    u32 h = canon * 0x9E3779B1u;   // (one multiply: quarter rate, and this runs once per base)
     h ^= h >> 15;
-    h *= 0x85EBCA77u;
-    h ^= h >> 13;
     return h;
 }
 __device__ __forceinline__ u32 slot_of(u32 minv, u32 nslots) {   // slot of a minimizer: independent of its rank
@@ -56,33 +77,76 @@ __device__ __forceinline__ u32 slot_of(u32 minv, u32 nslots) {   // slot of a mi
     x ^= x >> 15;
     return (u32)(((u64)x * (u64)nslots) >> 32);
 }
+// the value of the next lane (lane 63 keeps `old`): DPP wave_shl:1, no LDS round trip
+__device__ __forceinline__ u32 next_lane(u32 v, u32 old) {
+    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x130, 0xf, 0xf, false);
+}
+// v[s] for a run-time s < 32.  Per-lane register indexing does not exist; written as a tree of bit selects
+// (v_bfi) so that the compiler does not turn it into a scratch array.
+__device__ __forceinline__ u32 bsel(u32 m, u32 a, u32 b) { return (a & m) | (b & ~m); }   // m ? a : b, bitwise
+__device__ __forceinline__ u32 pick32(const u32 (&v)[SKM_PPT], u32 s) {
+    const u32 m0 = 0u - (s & 1u), m1 = 0u - ((s >> 1) & 1u), m2 = 0u - ((s >> 2) & 1u), m3 = 0u - ((s >> 3) & 1u),
+              m4 = 0u - ((s >> 4) & 1u);
+    u32 a[16], b[8], c[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = bsel(m0, v[2 * i + 1], v[2 * i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = bsel(m1, a[2 * i + 1], a[2 * i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = bsel(m2, b[2 * i + 1], b[2 * i]);
+    return bsel(m4, bsel(m3, c[3], c[2]), bsel(m3, c[1], c[0]));
+}
 
-// Sliding minimum over windows of L (a power of two) positions by doubling, in registers:
-// in: cur[0 .. PPT + L - 2], out: cur[j] = min(cur[j .. j + L - 1]) for j < PPT.
-template <int L>
-__device__ __forceinline__ void window_min(u32 (&cur)[SKM_PPT + SKM_MAXL - 1]) {
-    // after the level of stride s, cur[i] = min over 2s positions for i < PPT + L - 2s
+// Sliding minimum over windows of WW positions, in registers: in: cur[0 .. PPT + WW - 2], out: cur[j] =
+// min(cur[j .. j + WW - 1]) for j < PPT.  Doubling up to the largest power of two L <= WW, then two
+// overlapping windows of L.
+template <int WW>
+__device__ __forceinline__ void window_min(u32 (&cur)[SKM_PPT + WW - 1]) {
+    constexpr int L = WW >= 16 ? 16 : (WW >= 8 ? 8 : (WW >= 4 ? 4 : (WW >= 2 ? 2 : 1)));
+    constexpr int X = (int)SKM_PPT + WW - 1;   // extent
+    // after the level of stride s, cur[i] = min over 2s positions for i < X - (2s - 1)
 #pragma unroll
     for (int s = 1; s < L; s <<= 1) {
 #pragma unroll
-        for (int i = 0; i < (int)SKM_PPT + L - 2 * s; ++i) cur[i] = cur[i] < cur[i + s] ? cur[i] : cur[i + s];
+        for (int i = 0; i < X - (2 * s - 1); ++i) cur[i] = cur[i] < cur[i + s] ? cur[i] : cur[i + s];
+    }
+    constexpr int D = WW - L;
+    if (D) {
+#pragma unroll
+        for (int j = 0; j < (int)SKM_PPT; ++j) cur[j] = cur[j] < cur[j + D] ? cur[j] : cur[j + D];
     }
 }
 
 struct FlushLds {
-    uint4* stage;   // [SKM_CAP]
-    u16* sid;       // [SKM_CAP] bucket of every staged record
+    uint4* stage;   // [CAP]
+    u16* sid;       // [CAP] bucket of every staged record
     u32* bcnt;      // [nbk] records per bucket (zero on entry to a round)
     u32* bstart;    // [nbk + 1]
     u32* gpos;      // [nbk]
-    u32* wsum;      // [8]
+    u32* wsum;      // [16]
 };
+template <u32 CAP> __device__ __forceinline__ FlushLds flush_lds(u8* base, u32 nbk_alloc) {
+    FlushLds L;
+    L.stage = reinterpret_cast<uint4*>(base);
+    L.sid = reinterpret_cast<u16*>(base + (size_t)CAP * 16);
+    L.bcnt = reinterpret_cast<u32*>(base + (size_t)CAP * 18);
+    L.bstart = L.bcnt + nbk_alloc;
+    L.gpos = L.bstart + nbk_alloc + 4;
+    L.wsum = L.gpos + nbk_alloc;
+    return L;
+}
+template <u32 CAP> constexpr size_t flush_lds_bytes(u32 nbk_alloc) { return (size_t)CAP * 18 + (size_t)(3 * nbk_alloc + 4 + 16) * 4; }
 
-// Counting sort of the n staged records by bucket inside LDS, then every bucket's run goes to its region
-// (position from ONE returning global atomic per run), consecutive lanes storing consecutive records.
+// Counting sort of the n staged records by bucket inside LDS, then every bucket's run goes to its region,
+// consecutive lanes storing consecutive records.  The run's position comes from ONE returning global
+// atomic (LOCAL == false: the scatter, whose buckets are shared by all workgroups) or from a cursor in LDS
+// (LOCAL: the regroup, where a workgroup owns its buckets).  nbk <= 2 * NT.
 // Entry: a barrier has made stage / sid / bcnt visible.  Exit: bcnt zeroed, a barrier passed.
-__device__ __forceinline__ void skm_flush(const FlushLds& L, const u32 n, const u32 nbk, u32* __restrict__ cursors,
-                          uint4* __restrict__ region, const u32 region_cap, u32* __restrict__ ctl) {
+template <u32 NT, u32 CAP, bool LOCAL>
+__device__ __forceinline__ void skm_flush(const FlushLds& L, const u32 n, const u32 nbk, u32* cursors,
+                                          uint4* __restrict__ region, const u32 region_cap, u32* __restrict__ ctl) {
+    constexpr u32 CS = LOCAL ? 1u : KH_SKM_CUR1_STRIDE;   // words between two cursors
+    constexpr int RPT = (int)(CAP / NT);
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     // ---- exclusive scan of the bucket counts (two buckets per thread), run reservation
     u32 c0 = 0, c1 = 0;
@@ -92,25 +156,30 @@ __device__ __forceinline__ void skm_flush(const FlushLds& L, const u32 n, const 
     const u32 incl = wave_scan_add(c0 + c1);
     if (lane == KH_WAVE - 1) L.wsum[wid] = incl;
     if (c0) {
-        const u32 g = atomicAdd(&cursors[b0], c0);
+        u32 g;
+        if (LOCAL) { g = cursors[b0]; cursors[b0] = g + c0; }
+        else g = atomicAdd(&cursors[(size_t)b0 * CS], c0);
         L.gpos[b0] = g;
         if (g + c0 > region_cap) atomicOr(ctl, KH_ERR_CAPACITY);
     }
     if (c1) {
-        const u32 g = atomicAdd(&cursors[b1], c1);
+        u32 g;
+        if (LOCAL) { g = cursors[b1]; cursors[b1] = g + c1; }
+        else g = atomicAdd(&cursors[(size_t)b1 * CS], c1);
         L.gpos[b1] = g;
         if (g + c1 > region_cap) atomicOr(ctl, KH_ERR_CAPACITY);
     }
     // the staged records of this thread, into registers (they are placed in place)
-    u32 rx[SKM_RPT], ry[SKM_RPT], rz[SKM_RPT], rw[SKM_RPT], bk[SKM_RPT];
+    u32 rx[RPT], ry[RPT], rz[RPT], rw[RPT], bk[RPT];
 #pragma unroll
-    for (int r = 0; r < (int)SKM_RPT; ++r) {
-        const u32 i = tid + (u32)r * SKM_NT;
+    for (int r = 0; r < RPT; ++r) {
+        const u32 i = tid + (u32)r * NT;
         const uint4 v = L.stage[i < n ? i : 0];
         rx[r] = v.x; ry[r] = v.y; rz[r] = v.z; rw[r] = v.w;
         bk[r] = L.sid[i < n ? i : 0];
     }
     __syncthreads();
+    if (!LOCAL) SKM_STAMP(12);
     u32 run = incl - (c0 + c1);
     for (u32 w = 0; w < wid; ++w) run += L.wsum[w];
     if (b0 < nbk) { L.bstart[b0] = run; L.bcnt[b0] = 0; }
@@ -118,8 +187,8 @@ __device__ __forceinline__ void skm_flush(const FlushLds& L, const u32 n, const 
     __syncthreads();
     // ---- placement
 #pragma unroll
-    for (int r = 0; r < (int)SKM_RPT; ++r) {
-        const u32 i = tid + (u32)r * SKM_NT;
+    for (int r = 0; r < RPT; ++r) {
+        const u32 i = tid + (u32)r * NT;
         if (i < n) {
             const u32 at = L.bstart[bk[r]] + atomicAdd(&L.bcnt[bk[r]], 1u);
             L.stage[at] = make_uint4(rx[r], ry[r], rz[r], rw[r]);
@@ -127,10 +196,11 @@ __device__ __forceinline__ void skm_flush(const FlushLds& L, const u32 n, const 
         }
     }
     __syncthreads();
+    if (!LOCAL) SKM_STAMP(13);
     // ---- write-out
 #pragma unroll
-    for (int r = 0; r < (int)SKM_RPT; ++r) {
-        const u32 i = tid + (u32)r * SKM_NT;
+    for (int r = 0; r < RPT; ++r) {
+        const u32 i = tid + (u32)r * NT;
         if (i < n) {
             const u32 b = L.sid[i];
             const u32 dest = L.gpos[b] + (i - L.bstart[b]);
@@ -143,73 +213,106 @@ __device__ __forceinline__ void skm_flush(const FlushLds& L, const u32 n, const 
     __syncthreads();
 }
 
-__device__ __forceinline__ FlushLds flush_lds(u8* base, u32 nbk_alloc) {
-    FlushLds L;
-    L.stage = reinterpret_cast<uint4*>(base);
-    L.sid = reinterpret_cast<u16*>(base + (size_t)SKM_CAP * 16);
-    L.bcnt = reinterpret_cast<u32*>(base + (size_t)SKM_CAP * 18);
-    L.bstart = L.bcnt + nbk_alloc;
-    L.gpos = L.bstart + nbk_alloc + 4;
-    L.wsum = L.gpos + nbk_alloc;
-    return L;
+// the code words of one sub-tile, in flight while the previous one is processed
+struct SkmFetch { uint4 v[3]; u32 left[3]; };
+__device__ __forceinline__ void skm_fetch(const u8* __restrict__ sbase, const u64 len, const u64 p0, SkmFetch& f) {
+#pragma unroll
+    for (u32 r = 0; r < 3; ++r) {
+        const u32 w = threadIdx.x + r * SKM_NT;
+        f.left[r] = 0;
+        f.v[r] = make_uint4(0, 0, 0, 0);
+        if (w < SKM_CW) {
+            const u64 b0 = p0 + 16ull * w;
+            if (b0 < len) {
+                const u64 left = len - b0;
+                f.left[r] = left >= 16 ? 16u : (u32)left;
+                if (left >= 16) {
+                    f.v[r] = *reinterpret_cast<const uint4*>(sbase + b0);
+                } else {   // last, partial word of the sequence: never touch bytes past its end
+                    u32 w4[4] = {0, 0, 0, 0};
+                    for (u32 i = 0; i < (u32)left; ++i) w4[i >> 2] |= (u32)sbase[b0 + i] << (8 * (i & 3));
+                    f.v[r] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+            }
+        }
+    }
 }
-constexpr size_t flush_lds_bytes(u32 nbk_alloc) { return (size_t)SKM_CAP * 18 + (size_t)(3 * nbk_alloc + 4 + 8) * 4; }
+__device__ __forceinline__ void skm_store(const SkmFetch& f, u32* code, u16* bad16) {
+#pragma unroll
+    for (u32 r = 0; r < 3; ++r) {
+        const u32 w = threadIdx.x + r * SKM_NT;
+        if (w < SKM_CW) {
+            u32 codes = 0, bad = 0xffffu;
+            if (f.left[r]) {
+                decode16(f.v[r], codes, bad);
+                if (f.left[r] < 16) bad |= (0xffffu << f.left[r]) & 0xffffu;
+            }
+            code[w] = codes;
+            bad16[w] = (u16)bad;
+        }
+    }
+}
 
 }   // namespace
 
 size_t kh_skm_scatter_lds_bytes(u32 nb1) {
     const u32 nbk = (nb1 + 3) & ~3u;
-    return flush_lds_bytes(nbk) + (size_t)SKM_CW * 4 + (((size_t)SKM_CW * 2 + 15) & ~(size_t)15) +
-           (size_t)SKM_PPT * SKM_ROW * 4 + 96 * 4 + 64;
+    return flush_lds_bytes<SKM_CAP>(nbk) + (size_t)SKM_CW * 4 + (((size_t)SKM_CW * 2 + 15) & ~(size_t)15) + 64 * 4 + 4 * 32 * 4 + 64;
 }
-size_t kh_skm_regroup_lds_bytes(u32 S) { return flush_lds_bytes((S + 3) & ~3u) + 64; }
+size_t kh_skm_regroup_lds_bytes(u32 S) { return flush_lds_bytes<SKM_RG_CAP>((S + 3) & ~3u) + (size_t)((S + 3) & ~3u) * 4 + 64; }
 
 // ------------------------------------------------------------------------------------------
-// S1: bases -> records, partitioned by coarse bucket
+// S1: bases -> records, partitioned by coarse bucket.  WW = m-mers per k-mer (k - m + 1), compile time:
+// the sliding minimum is register arithmetic with constant indices.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SKM_NT, 2) void k_skm_scatter(const KhSkmJob jb) {
+template <int WW>
+__global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatter(const KhSkmJob jb) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     const u32 nbk = (jb.nb1 + 3) & ~3u;
-    const FlushLds L = flush_lds(lds_raw, nbk);
-    u8* p = lds_raw + flush_lds_bytes(nbk);
+    const FlushLds L = flush_lds<SKM_CAP>(lds_raw, nbk);
+    u8* p = lds_raw + flush_lds_bytes<SKM_CAP>(nbk);
     u32* code = reinterpret_cast<u32*>(p);                    p += (size_t)SKM_CW * 4;
     u16* bad16 = reinterpret_cast<u16*>(p);                   p += ((size_t)SKM_CW * 2 + 15) & ~(size_t)15;
-    u32* hT = reinterpret_cast<u32*>(p);                      p += (size_t)SKM_PPT * SKM_ROW * 4;   // [PPT][NT + 1], transposed
-    u32* tailh = reinterpret_cast<u32*>(p);                   p += 64 * 4;   // hashes of positions SUB .. SUB + 63
-    u32* taila = reinterpret_cast<u32*>(p);                   p += 32 * 4;   // window minima of positions SUB .. SUB + 31
-    u32* misc = reinterpret_cast<u32*>(p);                    // [0] staged records, [1] valid k-mers of the tile, [2..] scan scratch
+    u32* tailh = reinterpret_cast<u32*>(p);                   p += 64 * 4;       // hashes of positions SUB .. SUB + 63
+    u32* xch = reinterpret_cast<u32*>(p);                     p += 4 * 32 * 4;   // [wave][j]: hashes of the wave's first thread
+    u32* misc = reinterpret_cast<u32*>(p);                    // [1] valid k-mers of the tile, [2] scratch, [4..] scan scratch
 
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const KhTile t = jb.tiles[blockIdx.x];
     const KhSeg sg = jb.segs[t.seg];
     const int k = jb.k, m = jb.m;
-    const u32 w = jb.w, nslots = jb.nslots, S = jb.S, nmax = jb.nmax;
-    u32 Lw = 1;
-    while (2 * Lw <= w) Lw <<= 1;              // largest power of two <= w
-    const u32 d = w - Lw;
+    const u32 nslots = jb.nslots, S = jb.S, nmax = jb.nmax;
+    const u64 smagic = ((1ull << 40) + S - 1) / S;   // slot / S == (slot * smagic) >> 40 for slot < 2^20
     const u32 mmask = m >= 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
     const u64 tile_pos0 = (u64)t.tile_in_seg * jb.tile_pos;
     const int subtiles = (int)(jb.tile_pos / SKM_SUB);
 
     for (u32 i = tid; i < nbk; i += SKM_NT) L.bcnt[i] = 0;
-    if (tid < 2) misc[tid] = 0;
-    u32 staged = 0;   // uniform copy of misc[0]
+    if (tid < 4) misc[tid] = 0;
+    u32 staged = 0;   // uniform
 
+    SkmFetch pre;
+    skm_fetch(sg.seq, sg.len, tile_pos0, pre);
     for (int sub = 0; sub < subtiles; ++sub) {
         const u64 p0 = tile_pos0 + (u64)sub * SKM_SUB;
         if (p0 >= sg.npos) break;   // uniform
         __syncthreads();
-        load_codes<SKM_NT>(sg.seq, sg.len, p0, code, bad16, SKM_CW);
+        const bool stamp = sub == 1;
+        if (stamp) SKM_STAMP(0);
+        skm_store(pre, code, bad16);
         __syncthreads();
+        if (stamp) SKM_STAMP(1);
+        if (sub + 1 < subtiles && p0 + SKM_SUB < sg.npos) skm_fetch(sg.seq, sg.len, p0 + SKM_SUB, pre);
         // ---- hashes of the m-mers starting at the thread's 32 positions (32-bit rolling words)
         u32 cw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) cw[i] = code[2 * tid + i];
+        u32 cur[SKM_PPT + WW - 1];
         {
             const u32 pm = (u32)(m - 1);
-            const u32 pre = cw[0] & ((1u << (2 * pm)) - 1u);
-            u32 f = revpairs32(pre) >> (32 - 2 * pm);
-            u32 r = ((~pre) & ((1u << (2 * pm)) - 1u)) << 2;
+            const u32 pre_w = cw[0] & ((1u << (2 * pm)) - 1u);
+            u32 f = revpairs32(pre_w) >> (32 - 2 * pm);
+            u32 r = ((~pre_w) & ((1u << (2 * pm)) - 1u)) << 2;
             u32 nw[2];
             nw[0] = __builtin_amdgcn_alignbit(cw[1], cw[0], 2 * pm);
             nw[1] = __builtin_amdgcn_alignbit(cw[2], cw[1], 2 * pm);
@@ -218,56 +321,32 @@ __global__ __launch_bounds__(SKM_NT, 2) void k_skm_scatter(const KhSkmJob jb) {
                 const u32 c = (nw[j >> 4] >> (2 * (j & 15))) & 3u;
                 f = ((f << 2) | c) & mmask;
                 r = (r >> 2) | ((3u - c) << (2 * pm));
-                hT[(u32)j * SKM_ROW + tid] = mmer_hash(f < r ? f : r);
+                cur[j] = mmer_hash(f < r ? f : r);
             }
         }
-        if (tid < 64) {   // positions SUB .. SUB + 63, straight from the packed window
-            const u32 q = SKM_SUB + tid, wq = q >> 4, oq = q & 15u;
-            const u32 x0 = __builtin_amdgcn_alignbit(code[wq + 1], code[wq], 2 * oq);
-            const u32 x = x0 & mmask;
-            const u32 f = revpairs32(x) >> (32 - 2 * m);
-            const u32 r = (~x) & mmask;
-            tailh[tid] = mmer_hash(f < r ? f : r);
-        }
-        __syncthreads();
-        // ---- minimizer of every k-mer: minimum over its w m-mers
-        u32 cur[SKM_PPT + SKM_MAXL - 1];
-#pragma unroll
-        for (int j = 0; j < (int)SKM_PPT; ++j) cur[j] = hT[(u32)j * SKM_ROW + tid];
-        {
-            const bool last = tid == SKM_NT - 1;
-            const u32* hal = last ? tailh : (hT + tid + 1);
-            const u32 hs = last ? 1u : SKM_ROW;
-#pragma unroll
-            for (int j = 0; j < SKM_MAXL - 1; ++j) cur[SKM_PPT + j] = (u32)j < Lw - 1 ? hal[(u32)j * hs] : 0xffffffffu;
-        }
-        switch (Lw) {
-            case 1: break;
-            case 2: window_min<2>(cur); break;
-            case 4: window_min<4>(cur); break;
-            case 8: window_min<8>(cur); break;
-            default: window_min<16>(cur); break;
-        }
-        if (d) {   // w is not a power of two: two overlapping windows of Lw
-            if (tid < 32) {
-                u32 v = 0xffffffffu;
-                for (u32 i = 0; i < Lw; ++i) { const u32 x = tailh[tid + i]; v = x < v ? x : v; }
-                taila[tid] = v;
+        if (WW > 1) {
+            if (tid < 64) {   // positions SUB .. SUB + 63, straight from the packed window
+                const u32 q = SKM_SUB + tid, wq = q >> 4, oq = q & 15u;
+                const u32 x = __builtin_amdgcn_alignbit(code[wq + 1], code[wq], 2 * oq) & mmask;
+                const u32 f = revpairs32(x) >> (32 - 2 * m);
+                const u32 r = (~x) & mmask;
+                tailh[tid] = mmer_hash(f < r ? f : r);
             }
-            __syncthreads();   // every thread has read its hashes
+            if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j < (int)SKM_PPT; ++j) hT[(u32)j * SKM_ROW + tid] = cur[j];
+                for (int j = 0; j < WW - 1; ++j) xch[wid * 32 + j] = cur[j];
+            }
             __syncthreads();
-            const bool last = tid == SKM_NT - 1;
+            // the first WW - 1 hashes of the next thread: next lane, or the next wave's first thread
+            const u32* nx = wid + 1 < SKM_NT / 64 ? xch + (wid + 1) * 32 : tailh;
 #pragma unroll
-            for (int j = 0; j < (int)SKM_PPT; ++j) {
-                const u32 jd = (u32)j + d;
-                u32 o;
-                if (jd < SKM_PPT) o = hT[jd * SKM_ROW + tid];
-                else o = last ? taila[jd - SKM_PPT] : hT[(jd - SKM_PPT) * SKM_ROW + tid + 1];
-                cur[j] = cur[j] < o ? cur[j] : o;
+            for (int j = 0; j < WW - 1; ++j) {
+                const u32 edge = lane == KH_WAVE - 1 ? nx[j] : 0u;
+                cur[SKM_PPT + j] = next_lane(cur[j], edge);
             }
+            window_min<WW>(cur);
         }
+        if (stamp) SKM_STAMP(2);
         // ---- which of the 32 start positions have k valid bases
         u32 vm;
         {
@@ -279,17 +358,17 @@ __global__ __launch_bounds__(SKM_NT, 2) void k_skm_scatter(const KhSkmJob jb) {
             vm = ~(u32)bm;
         }
         // ---- slots; runs of valid positions with one slot become records
-        __syncthreads();   // hT is re-used for the slots of the positions
-        u32 cont = 0, prev = 0;
+        // (the hash is a bijection: equal minimizer hashes = one minimizer = one slot; the slot itself is
+        // worked out once per record)
+        u32 sl[SKM_PPT];
+        u32 cont = 0;
 #pragma unroll
         for (int j = 0; j < (int)SKM_PPT; ++j) {
-            const u32 s = slot_of(cur[j], nslots);
-            hT[(u32)j * SKM_ROW + tid] = s;
-            if (j && s == prev) cont |= 1u << j;
-            prev = s;
+            sl[j] = cur[j];
+            if (j && cur[j] == cur[j - 1]) cont |= 1u << j;
         }
         cont &= vm & (vm << 1);
-        u32 starts = vm & ~cont;
+        const u32 starts = vm & ~cont;
         auto run_len = [&](u32 s) -> u32 { return 1u + (u32)__builtin_ctzll(~((u64)cont >> (s + 1))); };
         u32 nrec = 0;
         {
@@ -305,7 +384,9 @@ __global__ __launch_bounds__(SKM_NT, 2) void k_skm_scatter(const KhSkmJob jb) {
             const u32 tot = wave_scan_add((u32)__popc(vm));
             if (lane == KH_WAVE - 1 && tot) atomicAdd(&misc[1], tot);
         }
+        if (stamp) SKM_STAMP(3);
         // ---- append to the staging array; a full array is flushed (a prefix of the threads fits)
+        if (stamp) SKM_STAMP(4);
         bool done = false;
         while (true) {
             const u32 mine = done ? 0u : nrec;
@@ -319,6 +400,7 @@ __global__ __launch_bounds__(SKM_NT, 2) void k_skm_scatter(const KhSkmJob jb) {
                 total += v;
             }
             const bool fits = staged + excl + mine <= SKM_CAP;
+            if (stamp) SKM_STAMP(9);
             if (!done && fits) {
                 u32 at = staged + excl;
                 u32 st = starts;
@@ -326,8 +408,8 @@ __global__ __launch_bounds__(SKM_NT, 2) void k_skm_scatter(const KhSkmJob jb) {
                     const u32 s = (u32)__builtin_ctz(st);
                     st &= st - 1;
                     u32 len = run_len(s);
-                    const u32 slot = hT[s * SKM_ROW + tid];
-                    const u32 coarse = slot / S, fine = slot - coarse * S;
+                    const u32 slot = slot_of(pick32(sl, s), nslots);
+                    const u32 coarse = (u32)(((u64)slot * smagic) >> 40), fine = slot - coarse * S;
                     for (u32 s2 = s; len; ) {
                         const u32 n = len < nmax ? len : nmax;
                         const u64 lo = ((u64)cw[1] << 32) | cw[0], hi = ((u64)cw[3] << 32) | cw[2];
@@ -349,11 +431,13 @@ __global__ __launch_bounds__(SKM_NT, 2) void k_skm_scatter(const KhSkmJob jb) {
                 done = true;
             }
             // records appended in this round: those of the fitting prefix of threads
+            if (stamp) SKM_STAMP(5);
             const u32 room = SKM_CAP - staged;
-            const u32 emitted = total <= room ? total : 0xffffffffu;   // all fitted: the common case
-            if (emitted != 0xffffffffu) {
+            if (total <= room) {   // all fitted: the common case
                 staged += total;
+                if (stamp) SKM_STAMP(6);
                 __syncthreads();
+                if (stamp) { SKM_STAMP(7); SKM_STAMP(8); }
                 break;
             }
             // some threads did not fit: the prefix that did ends at the largest excl + mine <= room
@@ -362,54 +446,82 @@ __global__ __launch_bounds__(SKM_NT, 2) void k_skm_scatter(const KhSkmJob jb) {
             if (fits && mine) atomicMax(&misc[2], excl + mine);
             __syncthreads();
             const u32 part = misc[2];
-            skm_flush(L, staged + part, jb.nb1, jb.cur1, jb.reg1, jb.cap1, jb.ctl);
+            if (stamp) SKM_STAMP(10);
+            skm_flush<SKM_NT, SKM_CAP, false>(L, staged + part, jb.nb1, jb.cur1, jb.reg1, jb.cap1, jb.ctl);
+            if (stamp) SKM_STAMP(11);
             staged = 0;
         }
     }
     __syncthreads();
-    if (staged) skm_flush(L, staged, jb.nb1, jb.cur1, jb.reg1, jb.cap1, jb.ctl);
+    if (staged) skm_flush<SKM_NT, SKM_CAP, false>(L, staged, jb.nb1, jb.cur1, jb.reg1, jb.cap1, jb.ctl);
     if (tid == 0 && misc[1]) atomicAdd(&jb.inst[t.seg], (unsigned long long)misc[1]);
 }
 
 // ------------------------------------------------------------------------------------------
-// S2a: the records of one coarse bucket, 2048 at a time, regrouped by fine slot
+// S2a: one workgroup per coarse bucket walks its records 8192 at a time and regroups them by fine slot.
+// The workgroup owns every slot of its bucket: the slot cursors live in LDS, no global atomic is needed.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SKM_NT, 3) void k_skm_regroup(const KhSkmJob jb) {
+__global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm_regroup(const KhSkmJob jb) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    constexpr int RPT = (int)(SKM_RG_CAP / SKM_RG_NT);
     const u32 nbk = (jb.S + 3) & ~3u;
-    const FlushLds L = flush_lds(lds_raw, nbk);
+    const FlushLds L = flush_lds<SKM_RG_CAP>(lds_raw, nbk);
+    u32* lcur = reinterpret_cast<u32*>(lds_raw + flush_lds_bytes<SKM_RG_CAP>(nbk));   // [nbk] records written per slot
     const u32 tid = threadIdx.x;
     const u32 b = blockIdx.x;
-    const u32 have = jb.cur1[b];
+    const u32 have = jb.cur1[(size_t)b * KH_SKM_CUR1_STRIDE];
     const u32 cnt = have < jb.cap1 ? have : jb.cap1;
-    const u32 start = blockIdx.y * SKM_CAP;
-    if (start >= cnt) return;   // uniform
-    const u32 n = cnt - start < SKM_CAP ? cnt - start : SKM_CAP;
-    for (u32 i = tid; i < nbk; i += SKM_NT) L.bcnt[i] = 0;
-    __syncthreads();
-    const uint4* __restrict__ src = jb.reg1 + (u64)b * jb.cap1 + start;
     const u32 first_slot = b * jb.S;
     const u32 nfine = jb.nslots - first_slot < jb.S ? jb.nslots - first_slot : jb.S;
+    for (u32 i = tid; i < nbk; i += SKM_RG_NT) { L.bcnt[i] = 0; lcur[i] = 0; }
+    const uint4* __restrict__ src = jb.reg1 + (u64)b * jb.cap1;
+    uint4* __restrict__ dst = jb.reg2 + (u64)first_slot * jb.cap2;
+    uint4 nx[RPT];
 #pragma unroll
-    for (u32 r = 0; r < SKM_RPT; ++r) {
-        const u32 i = tid + r * SKM_NT;
-        if (i < n) {
-            const uint4 rec = src[i];
-            u32 fine = (rec.w >> 12) & 511u;
-            if (fine >= nfine) { fine = 0; atomicOr(jb.ctl, KH_ERR_ORDER); }   // a corrupt record never leaves its bucket
-            L.stage[i] = rec;
-            L.sid[i] = (u16)fine;
-            atomicAdd(&L.bcnt[fine], 1u);
-        }
+    for (int r = 0; r < RPT; ++r) {
+        const u32 i = tid + (u32)r * SKM_RG_NT;
+        nx[r] = i < cnt ? src[i] : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    skm_flush(L, n, nfine, jb.cur2 + first_slot, jb.reg2 + (u64)first_slot * jb.cap2, jb.cap2, jb.ctl);
+    for (u32 start = 0; start < cnt; start += SKM_RG_CAP) {
+        const u32 n = cnt - start < SKM_RG_CAP ? cnt - start : SKM_RG_CAP;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const u32 i = tid + (u32)r * SKM_RG_NT;
+            if (i < n) {
+                u32 fine = (nx[r].w >> 12) & 511u;
+                if (fine >= nfine) { fine = 0; atomicOr(jb.ctl, KH_ERR_ORDER); }   // a corrupt record never leaves its bucket
+                L.stage[i] = nx[r];
+                L.sid[i] = (u16)fine;
+                atomicAdd(&L.bcnt[fine], 1u);
+            }
+        }
+        // the next round's records: in flight during the flush
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const u32 i = start + SKM_RG_CAP + tid + (u32)r * SKM_RG_NT;
+            nx[r] = i < cnt ? src[i] : make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        skm_flush<SKM_RG_NT, SKM_RG_CAP, true>(L, n, nfine, lcur, dst, jb.cap2, jb.ctl);
+    }
+    for (u32 i = tid; i < nfine; i += SKM_RG_NT) jb.cur2[first_slot + i] = lcur[i];
 }
 
 // ------------------------------------------------------------------------------------------
-// S2b: one slot per workgroup -> LDS hash set {canonical k-mer, genome mask} -> histogram bins
+// S2b: one slot per workgroup -> LDS hash set {canonical k-mer, genome mask} -> histogram bins.
+//
+// Records -> k-mers: a block scan of the records' k-mer counts numbers the slot's k-mers, and every thread
+// expands 8 CONSECUTIVE k-mer indices whatever records they fall in (chunk -> record table in LDS, the
+// records themselves re-read from L2): balanced lanes.
+// Insertion: rounds of 8 compare-and-swaps per thread.  A key gets KH_HASH_ROUNDS probes in the main table,
+// moves to a small second table with an independent hash, and from a full second table back to unbounded
+// probing of the main one; occupied entries stay occupied, so every copy of a key takes the same decisions as
+// the first.  (Measured and rejected: finishing the keys that lost round 1 one per lane in a loop — fewer
+// instructions, but a chain of ~20 dependent LDS round trips per wave: 2.63 ms against 2.30.)
 // ------------------------------------------------------------------------------------------
-constexpr u32 SKM_UNT = 512, SKM_UT = 4096, SKM_UE = SKM_UT / SKM_UNT, SKM_UT2 = SKM_UT / 16;
+constexpr u32 SKM_UNT = 512, SKM_UT = 4096, SKM_UE = SKM_UT / SKM_UNT, SKM_UT2 = 256;
+constexpr u32 SKM_UNW = SKM_UNT / 64;             // waves
 constexpr u32 SKM_URPT = 4;                       // records per thread when the slot is read: cap2 <= 4 * 512
 constexpr u32 SKM_OWN = 2048;                     // chunk owners: a slot of up to 8 * 2048 k-mer instances
 size_t kh_skm_union_lds_bytes(u32 nbins) {
@@ -422,16 +534,22 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
     constexpr u32 NT = SKM_UNT, T = SKM_UT, T2 = SKM_UT2, HBITS = 12;
     constexpr int E = (int)SKM_UE;
     constexpr u64 EMPTY = ~0ull;   // never a canonical key: the reverse complement of the all-T k-mer is 0
-    struct alignas(16) Ent { unsigned long long key, mask; };
+    // Table planes: keys (8-byte stride), low and high halves of the genome masks (4-byte stride).
+    struct Tbl { unsigned long long* key; u32* mlo; u32* mhi; };
     u8* p = lds_raw;
-    Ent* tbl = reinterpret_cast<Ent*>(p);                     p += (size_t)T * 16;
-    Ent* ovf = reinterpret_cast<Ent*>(p);                     p += (size_t)T2 * 16;
+    Tbl tbl, ovf;
+    tbl.key = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T * 8;
+    tbl.mlo = reinterpret_cast<u32*>(p);                      p += (size_t)T * 4;
+    tbl.mhi = reinterpret_cast<u32*>(p);                      p += (size_t)T * 4;
+    ovf.key = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T2 * 8;
+    ovf.mlo = reinterpret_cast<u32*>(p);                      p += (size_t)T2 * 4;
+    ovf.mhi = reinterpret_cast<u32*>(p);                      p += (size_t)T2 * 4;
     u32* ginfo = reinterpret_cast<u32*>(p);                   p += 256;
     u32* scratch = reinterpret_cast<u32*>(p);                 p += 128;
     u32* dupc = reinterpret_cast<u32*>(p);                    p += 256;
     u32* hstripe = reinterpret_cast<u32*>(p);                 p += ((size_t)jb.nbins * 32 + 15) & ~(size_t)15;
-    u16* roff = reinterpret_cast<u16*>(p);                    p += (size_t)(SKM_URPT * NT + 8) * 2;
-    u16* owner = reinterpret_cast<u16*>(p);
+    u16* roff = reinterpret_cast<u16*>(p);                    p += (size_t)(SKM_URPT * NT + 8) * 2;   // first k-mer index of every record
+    u16* owner = reinterpret_cast<u16*>(p);                   // [SKM_OWN] record that holds k-mer index 8c
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const u32 nbins = jb.nbins, cap2 = jb.cap2;
     const int k = jb.k;
@@ -446,16 +564,20 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
         rr[j] = i < cap2 ? reg[i] : make_uint4(0, 0, 0, 0);
     }
     auto clear_tables = [&]() {
-        uint4* t4 = reinterpret_cast<uint4*>(tbl);
+        uint4* k4 = reinterpret_cast<uint4*>(tbl.key);    // T * 8 bytes of ones, then T * 8 bytes of zeros (both mask planes)
+        uint4* m4 = reinterpret_cast<uint4*>(tbl.mlo);
 #pragma unroll
-        for (int e = 0; e < E; ++e) t4[(u32)e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
-        uint4* o4 = reinterpret_cast<uint4*>(ovf);
-        for (u32 i = tid; i < T2; i += NT) o4[i] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+        for (int e = 0; e < E / 2; ++e) {
+            k4[(u32)e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            m4[(u32)e * NT + tid] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        for (u32 i = tid; i < T2; i += NT) { ovf.key[i] = EMPTY; ovf.mlo[i] = 0u; ovf.mhi[i] = 0u; }
     };
     for (u32 i = tid; i < (u32)KH_TAG_MAX_OPS; i += NT) { ginfo[i] = jb.ginfo[i]; dupc[i] = 0; }
     for (u32 i = tid; i < nbins * 8u; i += NT) hstripe[i] = 0;
     clear_tables();
     const u32 nrec = have < cap2 ? have : cap2;
+    // ---- number the slot's k-mers: record i holds indices [roff[i], roff[i] + n_i)
     u32 nj[SKM_URPT], mine = 0;
 #pragma unroll
     for (u32 j = 0; j < SKM_URPT; ++j) {
@@ -464,15 +586,18 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
     }
     const u32 incl = wave_scan_add(mine);
     if (lane == KH_WAVE - 1) scratch[wid] = incl;
+    SKM_STAMP(0);
     __syncthreads();
+    SKM_STAMP(1);
     u32 off = incl - mine, N = 0;
-    for (u32 q = 0; q < NT / 64; ++q) {
+    for (u32 q = 0; q < SKM_UNW; ++q) {
         const u32 v = scratch[q];
         off += q < wid ? v : 0u;
         N += v;
     }
+    if (tid == 0 && N > T) atomicMax(jb.ctl + 1, N);
     if (N > 8u * SKM_OWN) {   // uniform: a slot this full goes back to the host
-        if (tid == 0) { atomicOr(jb.ctl, KH_ERR_CAPACITY); atomicMax(jb.ctl + 1, N); }
+        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
         N = 0;
     }
     if (N) {
@@ -486,6 +611,7 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
         }
     }
     __syncthreads();
+    SKM_STAMP(2);
     const u32 R = (N + T - 1) / T;   // key subsets handled one after the other (1 unless the slot is overfull)
     const u64 kmask = kh_mask(2 * k);
     auto eval_mask = [&](u64 mask, u32 g) -> u32 {
@@ -506,65 +632,70 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
     for (u32 q = 0; q < R; ++q) {
         if (q) { clear_tables(); __syncthreads(); }
         for (u32 base = 0; base < N; base += NT * (u32)E) {
-            const u32 j0 = base + (u32)E * tid;
-            u64 kreg[E];
-            u32 tagp[(E + 3) / 4], slot_[E], hh[E], act = 0;
+            {
+                const u32 j0 = base + (u32)E * tid;
+                u64 kreg[E];
+                u32 tagp[(E + 3) / 4], slot_[E], hh[E], act = 0;
 #pragma unroll
-            for (int w2 = 0; w2 < (E + 3) / 4; ++w2) tagp[w2] = 0;
-            if (j0 < N) {
-                u32 ri = owner[j0 >> 3];
-                u32 o = j0 - roff[ri];
-                const uint4 r0 = reg[ri];
-                const uint4 r1 = ri + 1 < nrec ? reg[ri + 1] : make_uint4(0, 0, 0, 0);
-                const uint4 r2 = ri + 2 < nrec ? reg[ri + 2] : make_uint4(0, 0, 0, 0);
-                u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
-                u32 cn = r0.w >> 27, ctag = (r0.w >> 21) & 63u, nxt = 1;
+                for (int w2 = 0; w2 < (E + 3) / 4; ++w2) tagp[w2] = 0;
+                if (j0 < N) {
+                    u32 ri = owner[j0 >> 3];
+                    u32 o = j0 - roff[ri];
+                    const uint4 r0 = reg[ri];
+                    uint4 q1 = ri + 1 < nrec ? reg[ri + 1] : make_uint4(0, 0, 0, 0);   // the two records behind it, in flight
+                    uint4 q2 = ri + 2 < nrec ? reg[ri + 2] : make_uint4(0, 0, 0, 0);
+                    u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
+                    u32 cn = r0.w >> 27, ctag = (r0.w >> 21) & 63u;
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    kreg[e] = EMPTY;
-                    hh[e] = 0;
-                    if (j0 + (u32)e < N) {
-                        if (o == cn) {
-                            ++ri;
-                            const uint4 r = nxt == 1 ? r1 : (nxt == 2 ? r2 : reg[ri < nrec ? ri : nrec - 1]);
-                            ++nxt;
-                            clo = ((u64)r.y << 32) | r.x;
-                            chi = ((u64)r.w << 32) | r.z;
-                            cn = r.w >> 27;
-                            ctag = (r.w >> 21) & 63u;
-                            o = 0;
+                    for (int e = 0; e < E; ++e) {
+                        kreg[e] = EMPTY;
+                        hh[e] = 0;
+                        if (j0 + (u32)e < N) {
+                            if (o == cn) {
+                                ++ri;
+                                uint4 r = q1;
+                                q1 = q2;
+                                q2 = make_uint4(0, 0, 0, 0);
+                                if (!(r.w >> 27)) r = reg[ri < nrec ? ri : nrec - 1];   // past the preloaded two (a record holds n >= 1)
+                                clo = ((u64)r.y << 32) | r.x;
+                                chi = ((u64)r.w << 32) | r.z;
+                                cn = r.w >> 27;
+                                ctag = (r.w >> 21) & 63u;
+                                o = 0;
+                            }
+                            const u32 sh = 2 * o;
+                            const u64 x = (sh ? (clo >> sh) | ((chi << 1) << (63 - sh)) : clo) & kmask;
+                            const u64 f = kh_revpairs64(x) >> (64 - 2 * k);
+                            const u64 rc = (~x) & kmask;
+                            const u64 can = f < rc ? f : rc;
+                            const u32 h = ((u32)can ^ (u32)(can >> 32)) * 0x9E3779B1u;
+                            kreg[e] = can;
+                            hh[e] = h;
+                            tagp[e >> 2] |= ctag << (8 * (e & 3));
+                            if (R == 1 || (((h >> 4) & 0xffffu) * R) >> 16 == q) act |= 1u << e;
+                            ++o;
                         }
-                        const u32 sh = 2 * o;
-                        const u64 x = (sh ? (clo >> sh) | ((chi << 1) << (63 - sh)) : clo) & kmask;
-                        const u64 f = kh_revpairs64(x) >> (64 - 2 * k);
-                        const u64 rc = (~x) & kmask;
-                        const u64 can = f < rc ? f : rc;
-                        const u32 h = ((u32)can ^ (u32)(can >> 32)) * 0x9E3779B1u;
-                        kreg[e] = can;
-                        hh[e] = h;
-                        tagp[e >> 2] |= ctag << (8 * (e & 3));
-                        if (R == 1 || (((h >> 4) & 0xffffu) * R) >> 16 == q) act |= 1u << e;
-                        ++o;
                     }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { kreg[e] = EMPTY; hh[e] = 0; }
                 }
-            } else {
+                auto tag = [&](int e) -> u32 { return (tagp[e >> 2] >> (8 * (e & 3))) & 63u; };
+                SKM_STAMP(3);
+                // ---- probe rounds, all of a thread's keys per round (one dependent LDS round trip per round)
+                u32 was[E];   // the half of the genome mask that holds this key's bit, as it was: bit set already = a repeat inside the genome
 #pragma unroll
-                for (int e = 0; e < E; ++e) { kreg[e] = EMPTY; hh[e] = 0; }
-            }
-            auto tag = [&](int e) -> u32 { return (tagp[e >> 2] >> (8 * (e & 3))) & 63u; };
-#pragma unroll
-            for (int e = 0; e < E; ++e) slot_[e] = hh[e] >> (32 - HBITS);
+                for (int e = 0; e < E; ++e) { slot_[e] = hh[e] >> (32 - HBITS); was[e] = 0u; }
 #define SKM_PROBE_ROUNDS(TBL, TMASK, ROUNDS)                                                                          \
     for (u32 round = 0; round < (ROUNDS) && __builtin_amdgcn_ballot_w64(act != 0); ++round) {                        \
         unsigned long long old[E];                                                                                    \
         _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                 \
-            old[e] = (act & (1u << e)) ? atomicCAS(&(TBL)[slot_[e]].key, EMPTY, (unsigned long long)kreg[e]) : 0ull;  \
+            old[e] = (act & (1u << e)) ? atomicCAS(&(TBL).key[slot_[e]], EMPTY, (unsigned long long)kreg[e]) : 0ull;  \
         _Pragma("unroll") for (int e = 0; e < E; ++e) {                                                               \
             if (act & (1u << e)) {                                                                                    \
                 if (old[e] == EMPTY || old[e] == kreg[e]) {                                                           \
-                    const unsigned long long bit = 1ull << tag(e);                                                    \
-                    const unsigned long long was = atomicOr(&(TBL)[slot_[e]].mask, bit);                              \
-                    if (was & bit) atomicAdd(&dupc[tag(e)], 1u);                                                      \
+                    was[e] = atomicOr(((tag(e) & 32u) ? (TBL).mhi : (TBL).mlo) + slot_[e],                            \
+                                      1u << (tag(e) & 31u));   /* looked at after the last round */                   \
                     act &= ~(1u << e);                                                                                \
                 } else {                                                                                              \
                     slot_[e] = (slot_[e] + 1u) & (TMASK);                                                             \
@@ -572,27 +703,72 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
             }                                                                                                         \
         }                                                                                                             \
     }
-            SKM_PROBE_ROUNDS(tbl, T - 1u, (u32)KH_HASH_ROUNDS)
-            if (__builtin_amdgcn_ballot_w64(act != 0)) {
+                SKM_PROBE_ROUNDS(tbl, T - 1u, (u32)KH_HASH_ROUNDS)
+                SKM_STAMP(9);
+#if KH_TUNE_SKM_OVF_SERIAL
+                // the few keys still homeless (~2 %): one per lane at a time, second table, then the main one again
+                while (__builtin_amdgcn_ballot_w64(act != 0)) {
+                    const bool have_one = act != 0;
+                    const u32 es = have_one ? (u32)__builtin_ctz(act) : 0u;
+                    u64 K = 0;
+                    u32 H = 0, tg = 0;
 #pragma unroll
-                for (int e = 0; e < E; ++e) slot_[e] = ((hh[e] ^ (hh[e] >> 15)) * 0x85EBCA77u) >> 24;   // T2 = 256
-                SKM_PROBE_ROUNDS(ovf, T2 - 1u, T2)
-                if (__builtin_amdgcn_ballot_w64(act != 0)) {   // second table full of other keys: on in the main table
-#pragma unroll
-                    for (int e = 0; e < E; ++e) slot_[e] = ((hh[e] >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
-                    SKM_PROBE_ROUNDS(tbl, T - 1u, T)
-                    if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                    for (int e = 0; e < E; ++e)
+                        if (es == (u32)e) { K = kreg[e]; H = hh[e]; tg = tag(e); }
+                    u32 S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> 24, probes = 0, level = 1, tmask = T2 - 1u;
+                    bool mine = have_one;
+                    while (__builtin_amdgcn_ballot_w64(mine)) {
+                        if (mine) {
+                            unsigned long long* kp = level == 1 ? ovf.key : tbl.key;
+                            const unsigned long long o2 = atomicCAS(&kp[S], EMPTY, (unsigned long long)K);
+                            if (o2 == EMPTY || o2 == K) {
+                                u32* mp = level == 1 ? ((tg & 32u) ? ovf.mhi : ovf.mlo) : ((tg & 32u) ? tbl.mhi : tbl.mlo);
+                                const u32 w = atomicOr(mp + S, 1u << (tg & 31u));
+                                if ((w >> (tg & 31u)) & 1u) atomicAdd(&dupc[tg], 1u);
+                                mine = false;
+                            } else {
+                                ++probes;
+                                if (level == 1 && probes >= T2) {
+                                    level = 2; probes = 0; tmask = T - 1u;
+                                    S = ((H >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
+                                } else if (level == 2 && probes >= T) {
+                                    atomicOr(jb.ctl, KH_ERR_CAPACITY);   // cannot happen: a round holds at most T keys
+                                    mine = false;
+                                } else {
+                                    S = (S + 1u) & tmask;
+                                }
+                            }
+                        }
+                    }
+                    if (have_one) act &= ~(1u << es);
                 }
-            }
+#endif
+                if (__builtin_amdgcn_ballot_w64(act != 0)) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) slot_[e] = ((hh[e] ^ (hh[e] >> 15)) * 0x85EBCA77u) >> 24;   // T2 = 256
+                    SKM_PROBE_ROUNDS(ovf, T2 - 1u, T2)
+                    if (__builtin_amdgcn_ballot_w64(act != 0)) {   // second table full of other keys: on in the main table
+#pragma unroll
+                        for (int e = 0; e < E; ++e) slot_[e] = ((hh[e] >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
+                        SKM_PROBE_ROUNDS(tbl, T - 1u, T)
+                        if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                    }
+                }
 #undef SKM_PROBE_ROUNDS
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if ((was[e] >> (tag(e) & 31u)) & 1u) atomicAdd(&dupc[tag(e)], 1u);
+                SKM_STAMP(4);
+            }
         }
         __syncthreads();
+        SKM_STAMP(5);
         // ---- every occupied entry is one distinct key of the slot: genome mask -> histogram bins
         u64 mk[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const Ent en = tbl[(u32)e * NT + tid];
-            mk[e] = en.key != EMPTY ? en.mask : 0ull;
+            const u32 i = (u32)e * NT + tid;
+            mk[e] = tbl.key[i] != EMPTY ? (((u64)tbl.mhi[i] << 32) | tbl.mlo[i]) : 0ull;
         }
         u32 gi[E];
 #pragma unroll
@@ -606,16 +782,18 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
             else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
         }
         for (u32 i = tid; i < T2; i += NT) {   // keys that moved to the second table (a few per slot)
-            const Ent en = ovf[i];
-            if (en.key != EMPTY) {
-                const u32 ng = eval_mask(en.mask, ginfo[__ffsll((unsigned long long)en.mask) - 1]);
+            if (ovf.key[i] != EMPTY) {
+                const u64 emask = ((u64)ovf.mhi[i] << 32) | ovf.mlo[i];
+                const u32 ng = eval_mask(emask, ginfo[__ffsll((unsigned long long)emask) - 1]);
                 if (ng == 1u) ++ones;
                 else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
             }
         }
         ones = wave_scan_add(ones);
         if (lane == KH_WAVE - 1 && ones) atomicAdd(&hstripe[(jb.abase + 1u) * 8u], ones);
+        SKM_STAMP(6);
         __syncthreads();
+        SKM_STAMP(7);
     }
     unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
     for (u32 i = tid; i < nbins; i += NT) {
@@ -625,6 +803,7 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
         if (v) atomicAdd(&rep[i], (unsigned long long)v);
     }
     if (tid < (u32)KH_TAG_MAX_OPS && dupc[tid]) atomicAdd(&jb.dup[tid], (unsigned long long)dupc[tid]);
+    SKM_STAMP(8);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -633,17 +812,26 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
 template <class K> static void skm_allow_lds(K kern, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+template <int WW> static void launch_scatter_w(const KhSkmJob& job, u32 ntiles, size_t lds, hipStream_t st) {
+    skm_allow_lds(k_skm_scatter<WW>, lds);
+    hipLaunchKernelGGL(k_skm_scatter<WW>, dim3(ntiles), dim3(SKM_NT), lds, st, job);
+}
+bool kh_skm_supports_w(u32 w) { return w >= (u32)SKM_WMIN && w <= (u32)SKM_WMAX; }
 void kh_launch_skm_scatter(const KhSkmJob& job, u32 ntiles, hipStream_t st) {
     if (!ntiles) return;
     const size_t lds = kh_skm_scatter_lds_bytes(job.nb1);
-    skm_allow_lds(k_skm_scatter, lds);
-    hipLaunchKernelGGL(k_skm_scatter, dim3(ntiles), dim3(SKM_NT), lds, st, job);
+    switch (job.w) {
+#define SKM_W(WW) case WW: launch_scatter_w<WW>(job, ntiles, lds, st); break;
+        SKM_W(5) SKM_W(6) SKM_W(7) SKM_W(8) SKM_W(9) SKM_W(10) SKM_W(11) SKM_W(12) SKM_W(13) SKM_W(14) SKM_W(15) SKM_W(16)
+        SKM_W(17) SKM_W(18)
+#undef SKM_W
+        default: break;   // the host asks kh_skm_supports_w first
+    }
 }
 void kh_launch_skm_regroup(const KhSkmJob& job, hipStream_t st) {
     const size_t lds = kh_skm_regroup_lds_bytes(job.S);
     skm_allow_lds(k_skm_regroup, lds);
-    const u32 chunks = (job.cap1 + SKM_CAP - 1) / SKM_CAP;
-    hipLaunchKernelGGL(k_skm_regroup, dim3(job.nb1, chunks), dim3(SKM_NT), lds, st, job);
+    hipLaunchKernelGGL(k_skm_regroup, dim3(job.nb1), dim3(SKM_RG_NT), lds, st, job);
 }
 void kh_launch_skm_union(const KhSkmJob& job, u32 cs, hipStream_t st) {
     const size_t lds = kh_skm_union_lds_bytes(job.nbins);

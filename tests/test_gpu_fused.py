@@ -13,6 +13,14 @@ from tests.util import random_dna
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def key_array_form(monkeypatch):
+    """This module tests the key-array form of the fused path (k_grid_bucket + k_union_hash /
+    k_union_tagged): still what runs for k < 20, k > 32, more than 64 genomes and emitted sets.  The
+    super-k-mer form that otherwise takes 20 <= k <= 32 has its own module (test_gpu_skm.py)."""
+    monkeypatch.setenv("KHOICE_NO_SKM", "1")
+
+
 @pytest.fixture(scope="module")
 def eng():
     from khoice_amd import build as kbuild
