@@ -77,6 +77,13 @@ def kernel_algorithmic_bytes(name, st, k, nseq_bases):
         total = st["setop_in"] * kb + st["setop_out"] * (kb + 4)
     elif name == "union_tagged":
         total = st["setop_in"] * kb                  # reads every genome set once; writes histograms only
+    # super-k-mer form (khoice_amd/csrc/kh_skm.hip): what each kernel has to move, R = 16-byte records
+    elif name == "skm_scatter":
+        total = steps_bases + st.get("skm_records", 0) * 16     # every base in, every record out
+    elif name == "skm_regroup":
+        total = st.get("skm_records", 0) * 32                    # every record in and out
+    elif name == "skm_union":
+        total = st.get("skm_records", 0) * 16                    # every record in; histograms out
     else:
         total = 0
     return total / launches
@@ -223,7 +230,9 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)}
     # whole K1 build against SURVEY §8d's compulsory figure N*1 + D*(8W+4)
     w = 1 if args.k <= 32 else 2
-    k1_ms = sum(kern[n]["ms"] for n in ("extract_hist", "bucket_plan", "extract_scatter", "bucket_sort_rle"))
+    # (the super-k-mer form builds no per-genome sets: its two partition kernels stand in for passes A-C)
+    k1_ms = sum(kern[n]["ms"] for n in ("extract_hist", "bucket_plan", "extract_scatter", "bucket_sort_rle",
+                                        "skm_scatter", "skm_regroup") if n in kern)
     k1_bytes = st["bases"] + st["distinct"] * (8 * w + 4)
     kernel_ms = {n: round(v["ms"] / args.steps, 4) for n, v in kern.items()}
     # whole path against SURVEY §8d's fused-path figure (read every base once, write every group

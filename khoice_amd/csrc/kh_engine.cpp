@@ -266,17 +266,17 @@ extern "C" int kh_stats(kh_ctx* c, char* buf, size_t buflen) {
     if (!c || !buf) return kh_fail(KH_E_ARG, "kh_stats: NULL argument");
     c->prof_collect();
     std::string s = "{";
-    char t[256];
+    char t[384];
     snprintf(t, sizeof t, "\"device\":%d,\"arch\":\"%s\",\"cus\":%d,", c->dev, c->arch.c_str(), c->cus);
     s += t;
     snprintf(t, sizeof t,
              "\"builds\":%llu,\"bases\":%llu,\"kmers\":%llu,\"distinct\":%llu,\"setops\":%llu,"
-             "\"setop_in\":%llu,\"setop_out\":%llu,\"retries\":%llu,\"order_fallbacks\":%llu,\"pool_bytes\":%zu,",
+             "\"setop_in\":%llu,\"setop_out\":%llu,\"retries\":%llu,\"order_fallbacks\":%llu,\"skm_records\":%llu,\"pool_bytes\":%zu,",
              (unsigned long long)c->stat.builds, (unsigned long long)c->stat.bases,
              (unsigned long long)c->stat.kmers, (unsigned long long)c->stat.distinct,
              (unsigned long long)c->stat.setops, (unsigned long long)c->stat.setop_in,
              (unsigned long long)c->stat.setop_out, (unsigned long long)c->stat.retries,
-             (unsigned long long)c->stat.order_fallbacks, c->pool.total_bytes);
+             (unsigned long long)c->stat.order_fallbacks, (unsigned long long)c->stat.skm_records, c->pool.total_bytes);
     s += t;
     s += "\"kernels\":{";
     for (int i = 0; i < KC_COUNT; ++i) {
@@ -1727,6 +1727,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     }
     c->stat.bases += bases;
     c->stat.builds += nseq;
+    c->stat.skm_records += h_ctl[2];
     u64 inst = 0, dsum = 0;
     for (int i = 0; i < nseq; ++i) {
         const u64 d = h_inst[i] - h_dup[i];

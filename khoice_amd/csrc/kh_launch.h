@@ -143,7 +143,7 @@ struct KhSkmJob {
     unsigned long long* dup;        // [64] instances whose (k-mer, genome) pair was seen before
     const u32* ginfo;               // as KhTagJob
     unsigned long long* hist;       // [reps][nbins]
-    u32* ctl;                       // [0] error bits, [1] fullest slot seen
+    u32* ctl;                       // [0] error bits, [1] fullest slot seen, [2] records written by the scatter
     u32 tile_pos;
     int k, m;                       // m-mer length of the minimizer (<= 16)
     u32 w;                          // m-mers per k-mer: k - m + 1

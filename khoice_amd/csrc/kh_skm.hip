@@ -43,8 +43,14 @@ void kh_debug_set_stamps_skm(u64* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_skm_
 #define SKM_STAMP(idx) do {} while (0)
 #endif
 
+#ifndef KH_TUNE_SKM_UNT
+#define KH_TUNE_SKM_UNT 1024    // threads of a union workgroup: two of them per CU = 8 waves per SIMD (512: 2.27 ms against 1.89)
+#endif
+#ifndef KH_TUNE_SKM_FULL_ROUNDS
+#define KH_TUNE_SKM_FULL_ROUNDS KH_TUNE_HASH_ROUNDS   // probe rounds made by all keys of a thread together; the rest one key per lane
+#endif
 #ifndef KH_TUNE_SKM_OVF_SERIAL
-#define KH_TUNE_SKM_OVF_SERIAL 0
+#define KH_TUNE_SKM_OVF_SERIAL 1
 #endif
 #ifndef KH_TUNE_SKM_SCATTER_WAVES
 #define KH_TUNE_SKM_SCATTER_WAVES 3   // waves per SIMD the scatter is compiled for (workgroups of 4 waves per CU)
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatt
 
     for (u32 i = tid; i < nbk; i += SKM_NT) L.bcnt[i] = 0;
     if (tid < 4) misc[tid] = 0;
-    u32 staged = 0;   // uniform
+    u32 staged = 0, tile_recs = 0;   // uniform
 
     SkmFetch pre;
     skm_fetch(sg.seq, sg.len, tile_pos0, pre);
@@ -385,9 +391,11 @@ __global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatt
             if (lane == KH_WAVE - 1 && tot) atomicAdd(&misc[1], tot);
         }
         if (stamp) SKM_STAMP(3);
-        // ---- append to the staging array; a full array is flushed (a prefix of the threads fits)
+        // ---- append to the staging array; a full array is flushed (a prefix of the threads fits).
+        // (Measured and not kept: descriptors first, then records built by all threads evenly — the same
+        // 0.77 ms, more registers.)
         if (stamp) SKM_STAMP(4);
-        bool done = false;
+        bool done = false, first_round = true;
         while (true) {
             const u32 mine = done ? 0u : nrec;
             const u32 incl = wave_scan_add(mine);
@@ -399,6 +407,7 @@ __global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatt
                 excl += q < wid ? v : 0u;
                 total += v;
             }
+            if (first_round) { tile_recs += total; first_round = false; }
             const bool fits = staged + excl + mine <= SKM_CAP;
             if (stamp) SKM_STAMP(9);
             if (!done && fits) {
@@ -455,6 +464,7 @@ __global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatt
     __syncthreads();
     if (staged) skm_flush<SKM_NT, SKM_CAP, false>(L, staged, jb.nb1, jb.cur1, jb.reg1, jb.cap1, jb.ctl);
     if (tid == 0 && misc[1]) atomicAdd(&jb.inst[t.seg], (unsigned long long)misc[1]);
+    if (tid == 0 && tile_recs) atomicAdd(jb.ctl + 2, tile_recs);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -520,16 +530,16 @@ __global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm_regroup(const KhSkmJob jb)
 // the first.  (Measured and rejected: finishing the keys that lost round 1 one per lane in a loop — fewer
 // instructions, but a chain of ~20 dependent LDS round trips per wave: 2.63 ms against 2.30.)
 // ------------------------------------------------------------------------------------------
-constexpr u32 SKM_UNT = 512, SKM_UT = 4096, SKM_UE = SKM_UT / SKM_UNT, SKM_UT2 = 256;
+constexpr u32 SKM_UNT = KH_TUNE_SKM_UNT, SKM_UT = 4096, SKM_UE = SKM_UT / SKM_UNT, SKM_UT2 = 256;
 constexpr u32 SKM_UNW = SKM_UNT / 64;             // waves
-constexpr u32 SKM_URPT = 4;                       // records per thread when the slot is read: cap2 <= 4 * 512
-constexpr u32 SKM_OWN = 2048;                     // chunk owners: a slot of up to 8 * 2048 k-mer instances
+constexpr u32 SKM_URPT = 2048 / SKM_UNT;           // records per thread when the slot is read: cap2 <= 2048
+constexpr u32 SKM_OWN = 2048;                     // chunk owners: a slot of up to SKM_UE * 2048 k-mer instances
 size_t kh_skm_union_lds_bytes(u32 nbins) {
     return (size_t)SKM_UT * 16 + (size_t)SKM_UT2 * 16 + 256 + 128 + 256 + (((size_t)nbins * 32 + 15) & ~(size_t)15) +
            (size_t)(SKM_URPT * SKM_UNT + 8) * 2 + (size_t)SKM_OWN * 2;
 }
 
-__global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32 cs) {
+__global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(const KhSkmJob jb, u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     constexpr u32 NT = SKM_UNT, T = SKM_UT, T2 = SKM_UT2, HBITS = 12;
     constexpr int E = (int)SKM_UE;
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
         N += v;
     }
     if (tid == 0 && N > T) atomicMax(jb.ctl + 1, N);
-    if (N > 8u * SKM_OWN) {   // uniform: a slot this full goes back to the host
+    if (N > (u32)SKM_UE * SKM_OWN) {   // uniform: a slot this full goes back to the host
         if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
         N = 0;
     }
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
         for (u32 j = 0; j < SKM_URPT; ++j) {
             if (nj[j]) {
                 roff[SKM_URPT * tid + j] = (u16)off;
-                for (u32 c = (off + 7) >> 3; c <= (off + nj[j] - 1) >> 3; ++c) owner[c] = (u16)(SKM_URPT * tid + j);
+                for (u32 c = (off + (u32)E - 1) / (u32)E; c <= (off + nj[j] - 1) / (u32)E; ++c) owner[c] = (u16)(SKM_URPT * tid + j);
                 off += nj[j];
             }
         }
@@ -639,7 +649,7 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
 #pragma unroll
                 for (int w2 = 0; w2 < (E + 3) / 4; ++w2) tagp[w2] = 0;
                 if (j0 < N) {
-                    u32 ri = owner[j0 >> 3];
+                    u32 ri = owner[j0 / (u32)E];
                     u32 o = j0 - roff[ri];
                     const uint4 r0 = reg[ri];
                     uint4 q1 = ri + 1 < nrec ? reg[ri + 1] : make_uint4(0, 0, 0, 0);   // the two records behind it, in flight
@@ -703,7 +713,7 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
             }                                                                                                         \
         }                                                                                                             \
     }
-                SKM_PROBE_ROUNDS(tbl, T - 1u, (u32)KH_HASH_ROUNDS)
+                SKM_PROBE_ROUNDS(tbl, T - 1u, (u32)KH_TUNE_SKM_FULL_ROUNDS)
                 SKM_STAMP(9);
 #if KH_TUNE_SKM_OVF_SERIAL
                 // the few keys still homeless (~2 %): one per lane at a time, second table, then the main one again
@@ -715,7 +725,12 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
 #pragma unroll
                     for (int e = 0; e < E; ++e)
                         if (es == (u32)e) { K = kreg[e]; H = hh[e]; tg = tag(e); }
+                    // level 0: the rest of the key's KH_HASH_ROUNDS probes in the main table, 1: second table, 2: main table, unbounded
                     u32 S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> 24, probes = 0, level = 1, tmask = T2 - 1u;
+                    if ((u32)KH_TUNE_SKM_FULL_ROUNDS < (u32)KH_HASH_ROUNDS) {
+                        S = ((H >> (32 - HBITS)) + (u32)KH_TUNE_SKM_FULL_ROUNDS) & (T - 1u);
+                        probes = (u32)KH_TUNE_SKM_FULL_ROUNDS; level = 0; tmask = T - 1u;
+                    }
                     bool mine = have_one;
                     while (__builtin_amdgcn_ballot_w64(mine)) {
                         if (mine) {
@@ -728,7 +743,10 @@ __global__ __launch_bounds__(SKM_UNT, 4) void k_skm_union(const KhSkmJob jb, u32
                                 mine = false;
                             } else {
                                 ++probes;
-                                if (level == 1 && probes >= T2) {
+                                if (level == 0 && probes >= (u32)KH_HASH_ROUNDS) {
+                                    level = 1; probes = 0; tmask = T2 - 1u;
+                                    S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> 24;
+                                } else if (level == 1 && probes >= T2) {
                                     level = 2; probes = 0; tmask = T - 1u;
                                     S = ((H >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
                                 } else if (level == 2 && probes >= T) {
