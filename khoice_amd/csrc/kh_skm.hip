@@ -49,6 +49,9 @@ void kh_debug_set_stamps_skm(u64* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_skm_
 #ifndef KH_TUNE_SKM_FULL_ROUNDS
 #define KH_TUNE_SKM_FULL_ROUNDS KH_TUNE_HASH_ROUNDS   // probe rounds made by all keys of a thread together; the rest one key per lane
 #endif
+#ifndef KH_TUNE_SKM_PREFETCH
+#define KH_TUNE_SKM_PREFETCH 0   // union: keep the record behind the current one in registers (four more VGPRs: spills at 64)
+#endif
 #ifndef KH_TUNE_SKM_OVF_SERIAL
 #define KH_TUNE_SKM_OVF_SERIAL 1
 #endif
@@ -533,11 +536,14 @@ __global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm_regroup(const KhSkmJob jb)
 constexpr u32 SKM_UNT = KH_TUNE_SKM_UNT, SKM_UT = 4096, SKM_UE = SKM_UT / SKM_UNT, SKM_UT2 = 256;
 constexpr u32 SKM_UNW = SKM_UNT / 64;             // waves
 constexpr u32 SKM_URPT = 2048 / SKM_UNT;           // records per thread when the slot is read: cap2 <= 2048
+constexpr u32 SKM_SPEC = 576;                     // records of a slot read before their number is known (mean ~420)
 constexpr u32 SKM_OWN = 2048;                     // chunk owners: a slot of up to SKM_UE * 2048 k-mer instances
 size_t kh_skm_union_lds_bytes(u32 nbins) {
     return (size_t)SKM_UT * 16 + (size_t)SKM_UT2 * 16 + 256 + 128 + 256 + (((size_t)nbins * 32 + 15) & ~(size_t)15) +
            (size_t)(SKM_URPT * SKM_UNT + 8) * 2 + (size_t)SKM_OWN * 2;
 }
+
+__device__ __forceinline__ u32 key_hash(u64 can) { return ((u32)can ^ (u32)(can >> 32)) * 0x9E3779B1u; }
 
 __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(const KhSkmJob jb, u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
@@ -565,13 +571,15 @@ __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(c
     const int k = jb.k;
     const u32 slot = blockIdx.x;
     const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2;
-    // ---- the slot's records: four per thread, requested before their number is known
+    // ---- the slot's records, SKM_URPT consecutive ones per thread.  Their number is not known yet: the first
+    // SKM_SPEC (more than nearly every slot holds) are requested together with it, the others once it is
+    // (reading the whole region up to its capacity moved 2.5x the records' bytes).
     const u32 have = jb.cur2[slot];
     uint4 rr[SKM_URPT];
 #pragma unroll
     for (u32 j = 0; j < SKM_URPT; ++j) {
         const u32 i = SKM_URPT * tid + j;
-        rr[j] = i < cap2 ? reg[i] : make_uint4(0, 0, 0, 0);
+        rr[j] = i < (cap2 < SKM_SPEC ? cap2 : SKM_SPEC) ? reg[i] : make_uint4(0, 0, 0, 0);
     }
     auto clear_tables = [&]() {
         uint4* k4 = reinterpret_cast<uint4*>(tbl.key);    // T * 8 bytes of ones, then T * 8 bytes of zeros (both mask planes)
@@ -581,12 +589,21 @@ __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(c
             k4[(u32)e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
             m4[(u32)e * NT + tid] = make_uint4(0u, 0u, 0u, 0u);
         }
-        for (u32 i = tid; i < T2; i += NT) { ovf.key[i] = EMPTY; ovf.mlo[i] = 0u; ovf.mhi[i] = 0u; }
+        unsigned long long e0 = EMPTY;   // (opaque, as `emptyv` below)
+        asm volatile("" : "+v"(e0));
+        for (u32 i = tid; i < T2; i += NT) { ovf.key[i] = e0; ovf.mlo[i] = 0u; ovf.mhi[i] = 0u; }
     };
     for (u32 i = tid; i < (u32)KH_TAG_MAX_OPS; i += NT) { ginfo[i] = jb.ginfo[i]; dupc[i] = 0; }
     for (u32 i = tid; i < nbins * 8u; i += NT) hstripe[i] = 0;
     clear_tables();
     const u32 nrec = have < cap2 ? have : cap2;
+    if (nrec > SKM_SPEC) {   // uniform, rare
+#pragma unroll
+        for (u32 j = 0; j < SKM_URPT; ++j) {
+            const u32 i = SKM_URPT * tid + j;
+            if (i >= SKM_SPEC && i < nrec) rr[j] = reg[i];
+        }
+    }
     // ---- number the slot's k-mers: record i holds indices [roff[i], roff[i] + n_i)
     u32 nj[SKM_URPT], mine = 0;
 #pragma unroll
@@ -641,32 +658,38 @@ __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(c
     };
     for (u32 q = 0; q < R; ++q) {
         if (q) { clear_tables(); __syncthreads(); }
+        unsigned long long emptyv = EMPTY;   // (opaque: made here, or the compiler keeps the constant in two VGPRs across the loop and spills it)
+        asm volatile("" : "+v"(emptyv));
         for (u32 base = 0; base < N; base += NT * (u32)E) {
             {
                 const u32 j0 = base + (u32)E * tid;
                 u64 kreg[E];
-                u32 tagp[(E + 3) / 4], slot_[E], hh[E], act = 0;
+                u32 tagp[(E + 3) / 4], slot_[E], act = 0;
 #pragma unroll
                 for (int w2 = 0; w2 < (E + 3) / 4; ++w2) tagp[w2] = 0;
                 if (j0 < N) {
                     u32 ri = owner[j0 / (u32)E];
                     u32 o = j0 - roff[ri];
                     const uint4 r0 = reg[ri];
-                    uint4 q1 = ri + 1 < nrec ? reg[ri + 1] : make_uint4(0, 0, 0, 0);   // the two records behind it, in flight
-                    uint4 q2 = ri + 2 < nrec ? reg[ri + 2] : make_uint4(0, 0, 0, 0);
+#if KH_TUNE_SKM_PREFETCH
+                    uint4 q1 = ri + 1 < nrec ? reg[ri + 1] : make_uint4(0, 0, 0, 0);   // the record behind it, in flight
+#endif
                     u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
                     u32 cn = r0.w >> 27, ctag = (r0.w >> 21) & 63u;
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         kreg[e] = EMPTY;
-                        hh[e] = 0;
+                        slot_[e] = 0;
                         if (j0 + (u32)e < N) {
                             if (o == cn) {
                                 ++ri;
+#if KH_TUNE_SKM_PREFETCH
                                 uint4 r = q1;
-                                q1 = q2;
-                                q2 = make_uint4(0, 0, 0, 0);
-                                if (!(r.w >> 27)) r = reg[ri < nrec ? ri : nrec - 1];   // past the preloaded two (a record holds n >= 1)
+                                q1 = make_uint4(0, 0, 0, 0);
+                                if (!(r.w >> 27)) r = reg[ri < nrec ? ri : nrec - 1];   // past the preloaded one (a record holds n >= 1)
+#else
+                                const uint4 r = reg[ri < nrec ? ri : nrec - 1];   // an L2 hit: the records were read a moment ago
+#endif
                                 clo = ((u64)r.y << 32) | r.x;
                                 chi = ((u64)r.w << 32) | r.z;
                                 cn = r.w >> 27;
@@ -678,9 +701,9 @@ __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(c
                             const u64 f = kh_revpairs64(x) >> (64 - 2 * k);
                             const u64 rc = (~x) & kmask;
                             const u64 can = f < rc ? f : rc;
-                            const u32 h = ((u32)can ^ (u32)(can >> 32)) * 0x9E3779B1u;
+                            const u32 h = key_hash(can);
                             kreg[e] = can;
-                            hh[e] = h;
+                            slot_[e] = h >> (32 - HBITS);
                             tagp[e >> 2] |= ctag << (8 * (e & 3));
                             if (R == 1 || (((h >> 4) & 0xffffu) * R) >> 16 == q) act |= 1u << e;
                             ++o;
@@ -688,22 +711,22 @@ __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(c
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) { kreg[e] = EMPTY; hh[e] = 0; }
+                    for (int e = 0; e < E; ++e) { kreg[e] = EMPTY; slot_[e] = 0; }
                 }
                 auto tag = [&](int e) -> u32 { return (tagp[e >> 2] >> (8 * (e & 3))) & 63u; };
                 SKM_STAMP(3);
                 // ---- probe rounds, all of a thread's keys per round (one dependent LDS round trip per round)
                 u32 was[E];   // the half of the genome mask that holds this key's bit, as it was: bit set already = a repeat inside the genome
 #pragma unroll
-                for (int e = 0; e < E; ++e) { slot_[e] = hh[e] >> (32 - HBITS); was[e] = 0u; }
+                for (int e = 0; e < E; ++e) was[e] = 0u;
 #define SKM_PROBE_ROUNDS(TBL, TMASK, ROUNDS)                                                                          \
     for (u32 round = 0; round < (ROUNDS) && __builtin_amdgcn_ballot_w64(act != 0); ++round) {                        \
         unsigned long long old[E];                                                                                    \
         _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                 \
-            old[e] = (act & (1u << e)) ? atomicCAS(&(TBL).key[slot_[e]], EMPTY, (unsigned long long)kreg[e]) : 0ull;  \
+            old[e] = (act & (1u << e)) ? atomicCAS(&(TBL).key[slot_[e]], emptyv, (unsigned long long)kreg[e]) : 0ull;  \
         _Pragma("unroll") for (int e = 0; e < E; ++e) {                                                               \
             if (act & (1u << e)) {                                                                                    \
-                if (old[e] == EMPTY || old[e] == kreg[e]) {                                                           \
+                if (old[e] == emptyv || old[e] == kreg[e]) {                                                           \
                     was[e] = atomicOr(((tag(e) & 32u) ? (TBL).mhi : (TBL).mlo) + slot_[e],                            \
                                       1u << (tag(e) & 31u));   /* looked at after the last round */                   \
                     act &= ~(1u << e);                                                                                \
@@ -721,10 +744,11 @@ __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(c
                     const bool have_one = act != 0;
                     const u32 es = have_one ? (u32)__builtin_ctz(act) : 0u;
                     u64 K = 0;
-                    u32 H = 0, tg = 0;
+                    u32 tg = 0;
 #pragma unroll
                     for (int e = 0; e < E; ++e)
-                        if (es == (u32)e) { K = kreg[e]; H = hh[e]; tg = tag(e); }
+                        if (es == (u32)e) { K = kreg[e]; tg = tag(e); }
+                    const u32 H = key_hash(K);
                     // level 0: the rest of the key's KH_HASH_ROUNDS probes in the main table, 1: second table, 2: main table, unbounded
                     u32 S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> 24, probes = 0, level = 1, tmask = T2 - 1u;
                     if ((u32)KH_TUNE_SKM_FULL_ROUNDS < (u32)KH_HASH_ROUNDS) {
@@ -735,8 +759,8 @@ __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(c
                     while (__builtin_amdgcn_ballot_w64(mine)) {
                         if (mine) {
                             unsigned long long* kp = level == 1 ? ovf.key : tbl.key;
-                            const unsigned long long o2 = atomicCAS(&kp[S], EMPTY, (unsigned long long)K);
-                            if (o2 == EMPTY || o2 == K) {
+                            const unsigned long long o2 = atomicCAS(&kp[S], emptyv, (unsigned long long)K);
+                            if (o2 == emptyv || o2 == K) {
                                 u32* mp = level == 1 ? ((tg & 32u) ? ovf.mhi : ovf.mlo) : ((tg & 32u) ? tbl.mhi : tbl.mlo);
                                 const u32 w = atomicOr(mp + S, 1u << (tg & 31u));
                                 if ((w >> (tg & 31u)) & 1u) atomicAdd(&dupc[tg], 1u);
@@ -763,11 +787,11 @@ __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(c
 #endif
                 if (__builtin_amdgcn_ballot_w64(act != 0)) {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) slot_[e] = ((hh[e] ^ (hh[e] >> 15)) * 0x85EBCA77u) >> 24;   // T2 = 256
+                    for (int e = 0; e < E; ++e) { const u32 h = key_hash(kreg[e]); slot_[e] = ((h ^ (h >> 15)) * 0x85EBCA77u) >> 24; }   // T2 = 256
                     SKM_PROBE_ROUNDS(ovf, T2 - 1u, T2)
                     if (__builtin_amdgcn_ballot_w64(act != 0)) {   // second table full of other keys: on in the main table
 #pragma unroll
-                        for (int e = 0; e < E; ++e) slot_[e] = ((hh[e] >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
+                        for (int e = 0; e < E; ++e) slot_[e] = ((key_hash(kreg[e]) >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
                         SKM_PROBE_ROUNDS(tbl, T - 1u, T)
                         if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
                     }
@@ -782,10 +806,15 @@ __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(c
         __syncthreads();
         SKM_STAMP(5);
         // ---- every occupied entry is one distinct key of the slot: genome mask -> histogram bins
+        // (the thread number through an opaque copy: addresses formed from it are worked out here, not kept in
+        // registers across the insertion loop — where the compiler spilled them, 28 bytes of scratch per
+        // thread = 1.5 GB of HBM writes per step)
+        u32 tid_ro = tid;
+        asm volatile("" : "+v"(tid_ro));
         u64 mk[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const u32 i = (u32)e * NT + tid;
+            const u32 i = (u32)e * NT + tid_ro;
             mk[e] = tbl.key[i] != EMPTY ? (((u64)tbl.mhi[i] << 32) | tbl.mlo[i]) : 0ull;
         }
         u32 gi[E];
@@ -799,7 +828,7 @@ __global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(c
             if (ng == 1u) ++ones;
             else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
         }
-        for (u32 i = tid; i < T2; i += NT) {   // keys that moved to the second table (a few per slot)
+        for (u32 i = tid_ro; i < T2; i += NT) {   // keys that moved to the second table (a few per slot)
             if (ovf.key[i] != EMPTY) {
                 const u64 emask = ((u64)ovf.mhi[i] << 32) | ovf.mlo[i];
                 const u32 ng = eval_mask(emask, ginfo[__ffsll((unsigned long long)emask) - 1]);
