@@ -228,6 +228,24 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_stale": traffic_stale,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)}
+    # The dominant kernel of the super-k-mer form is bound by vector instruction issue, not by HBM: when the SQ
+    # counter file was collected on exactly these sources (tools/pmc_sq.sh), report its wave instructions per
+    # second against the chip's issue rate (256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at the
+    # 2.4 GHz peak clock; MI355X_MICROARCH.md, instruction issue costs).
+    issue = None
+    spath = os.path.join(ROOT, "profiles", "sq_counters.json")
+    if os.path.exists(spath):
+        try:
+            sj = json.load(open(spath))
+            if sj.get("_source_sha") == source_hash() and hot in sj and avg_ms > 0:
+                valu = sj[hot].get("SQ_INSTS_VALU", 0)
+                peak = 256 * 4 * 2.4e9 / 4
+                issue = {"bound": "valu_issue", "kernel": hot, "wave_instructions_per_launch": int(valu),
+                         "achieved": round(valu / (avg_ms * 1e-3) / 1e9, 1), "peak": round(peak / 1e9, 1),
+                         "unit": "G wave-instr/s", "frac": round(valu / (avg_ms * 1e-3) / peak, 4),
+                         "sq_wait_any_share": round(sj[hot].get("SQ_WAIT_ANY", 0) / max(1, sj[hot].get("SQ_WAVE_CYCLES", 1)), 3)}
+        except Exception:
+            issue = None
     # whole K1 build against SURVEY §8d's compulsory figure N*1 + D*(8W+4)
     w = 1 if args.k <= 32 else 2
     # (the super-k-mer form builds no per-genome sets: its two partition kernels stand in for passes A-C)
@@ -270,6 +288,7 @@ def main():
                               "frac": round(k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k1_ms else 0.0,
                               "unit": "GB/s"},
         "path_roofline": path_roofline,
+        "issue_roofline": issue,
         "kernel_ms_per_step": kernel_ms,
         "replans": st["retries"], "order_fallbacks": st.get("order_fallbacks", 0),
         "setup_seconds": round(gen_s, 1),

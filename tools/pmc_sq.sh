@@ -6,16 +6,4 @@ OUT=gpurun_out/pmc_$TAG
 rm -rf $OUT && mkdir -p $OUT
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/a.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM --kernel-trace --output-format csv -d $OUT/b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/b.log 2>&1
-python3 - $OUT <<'PY'
-import csv,glob,sys,collections
-out=sys.argv[1]
-for sub in ("a","b"):
-    acc=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
-    for f in glob.glob(f"{out}/{sub}/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            k=r["Kernel_Name"].split("(")[0][:40]
-            acc[k][r["Counter_Name"]]+=float(r["Counter_Value"]); 
-    for k,v in acc.items():
-        if "skm" in k or "union" in k or "extract" in k or "grid" in k:
-            print(sub,k,{c:f"{x:.3g}" for c,x in v.items()})
-PY
+python3 tools/summarize_sq.py $OUT $TAG

@@ -10,7 +10,6 @@ import json
 import shutil
 import sys
 
-out, tag = sys.argv[1], sys.argv[2]
 CLASS = {"k_extract<1, false>": "extract_hist", "k_extract<2, false>": "extract_hist",
          "k_extract_staged": "extract_scatter", "k_extract<1, true>": "extract_scatter",
          "k_extract<2, true>": "extract_scatter", "k_bucket_sort_rle": "bucket_sort_rle",
@@ -26,37 +25,40 @@ def cls(name):
     return None
 
 
-stats = glob.glob(f"{out}/stats/*/*kernel_stats.csv")
-if stats:
-    shutil.copy(stats[0], f"gpurun_out/{tag}_kernel_stats.csv")
-traffic = collections.defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0, "launches": 0})
-for kind in ("fetch", "write"):
-    files = glob.glob(f"{out}/{kind}/*/*counter_collection.csv")
-    if not files:
-        continue
-    seen = collections.Counter()
-    for r in csv.DictReader(open(files[0])):
-        c = cls(r["Kernel_Name"])
-        if not c:
+
+if __name__ == "__main__":
+    out, tag = sys.argv[1], sys.argv[2]
+    stats = glob.glob(f"{out}/stats/*/*kernel_stats.csv")
+    if stats:
+        shutil.copy(stats[0], f"gpurun_out/{tag}_kernel_stats.csv")
+    traffic = collections.defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0, "launches": 0})
+    for kind in ("fetch", "write"):
+        files = glob.glob(f"{out}/{kind}/*/*counter_collection.csv")
+        if not files:
             continue
-        traffic[c][f"{kind}_kb"] += float(r["Counter_Value"])
-        seen[c] += 1
-    for c, n in seen.items():
-        traffic[c]["launches"] = n
-res = {}
-for c, t in traffic.items():
-    n = max(1, t["launches"])
-    res[c] = {"launches_profiled": n,
-              "fetch_bytes_per_launch": int(2 * t["fetch_kb"] * 1024 / n),
-              "write_bytes_per_launch": int(t["write_kb"] * 1024 / n)}
-    res[c]["bytes_per_launch"] = res[c]["fetch_bytes_per_launch"] + res[c]["write_bytes_per_launch"]
-# the sources these counters were collected on (bench.py refuses the file for any other sources)
-import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import source_hash  # noqa: E402
-res["_source_sha"] = source_hash()
-steps_profiled = 3          # collect_profiles.sh: --steps 2 --warmup 1 in the PMC passes
-res["_bytes_per_step"] = int(sum(v["bytes_per_launch"] * v["launches_profiled"] for k, v in res.items()
-                                 if isinstance(v, dict)) / steps_profiled)
-json.dump(res, open(f"gpurun_out/{tag}_hbm_traffic.json", "w"), indent=1)
-print(json.dumps(res, indent=1))
+        seen = collections.Counter()
+        for r in csv.DictReader(open(files[0])):
+            c = cls(r["Kernel_Name"])
+            if not c:
+                continue
+            traffic[c][f"{kind}_kb"] += float(r["Counter_Value"])
+            seen[c] += 1
+        for c, n in seen.items():
+            traffic[c]["launches"] = n
+    res = {}
+    for c, t in traffic.items():
+        n = max(1, t["launches"])
+        res[c] = {"launches_profiled": n,
+                  "fetch_bytes_per_launch": int(2 * t["fetch_kb"] * 1024 / n),
+                  "write_bytes_per_launch": int(t["write_kb"] * 1024 / n)}
+        res[c]["bytes_per_launch"] = res[c]["fetch_bytes_per_launch"] + res[c]["write_bytes_per_launch"]
+    # the sources these counters were collected on (bench.py refuses the file for any other sources)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_hash  # noqa: E402
+    res["_source_sha"] = source_hash()
+    steps_profiled = 3          # collect_profiles.sh: --steps 2 --warmup 1 in the PMC passes
+    res["_bytes_per_step"] = int(sum(v["bytes_per_launch"] * v["launches_profiled"] for k, v in res.items()
+                                     if isinstance(v, dict)) / steps_profiled)
+    json.dump(res, open(f"gpurun_out/{tag}_hbm_traffic.json", "w"), indent=1)
+    print(json.dumps(res, indent=1))
