@@ -313,9 +313,9 @@ __global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatt
         if (stamp) SKM_STAMP(1);
         if (sub + 1 < subtiles && p0 + SKM_SUB < sg.npos) skm_fetch(sg.seq, sg.len, p0 + SKM_SUB, pre);
         // ---- hashes of the m-mers starting at the thread's 32 positions (32-bit rolling words)
-        u32 cw[4];
+        u32 cw[6];   // bases p .. p + 95: a record starts in the thread's 32 positions and may run on into the next thread's
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cw[i] = code[2 * tid + i];
+        for (int i = 0; i < 6; ++i) cw[i] = code[2 * tid + i];
         u32 cur[SKM_PPT + WW - 1];
         {
             const u32 pm = (u32)(m - 1);
@@ -377,8 +377,22 @@ __global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatt
             if (j && cur[j] == cur[j - 1]) cont |= 1u << j;
         }
         cont &= vm & (vm << 1);
-        const u32 starts = vm & ~cont;
-        auto run_len = [&](u32 s) -> u32 { return 1u + (u32)__builtin_ctzll(~((u64)cont >> (s + 1))); };
+        // A run may go on into the NEXT thread of the wave (not past the wave's 2048 positions, not over more than
+        // one boundary, not beyond nmax k-mers): then its record belongs to the thread it starts in, and the next
+        // thread's leading positions are not starts.  Down the wave: minimizer and length of my last run; back up:
+        // how many of the next thread's positions join it.  (Records cut at every 32 positions held 6.8 k-mers
+        // where the minimizer runs average 8.5.)
+        const u32 tr = (vm >> 31) ? 1u + (u32)__builtin_clz(~cont | 1u) : 0u;            // my last run's k-mers (32: all of mine)
+        const u32 lead = 1u + (u32)__builtin_ctz(~(cont >> 1));                            // positions 0 .. lead-1 continue position 0's run
+        const u32 p_min = (u32)__builtin_amdgcn_update_dpp(0, (int)cur[SKM_PPT - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
+        const u32 p_tr = (u32)__builtin_amdgcn_update_dpp(0, (int)tr, 0x138, 0xf, 0xf, false);
+        const bool merge_in = lane != 0 && p_tr != 0 && (vm & 1u) && p_min == cur[0] && p_tr + lead <= nmax;
+        const u32 ext = next_lane(merge_in ? lead : 0u, 0u);   // k-mers of the next thread that join my last run
+        const u32 starts = (vm & ~cont) & ~(merge_in ? 1u : 0u);
+        auto run_len = [&](u32 s) -> u32 {
+            const u32 len = 1u + (u32)__builtin_ctzll(~((u64)cont >> (s + 1)));
+            return s + len == SKM_PPT ? len + ext : len;
+        };
         u32 nrec = 0;
         {
             u32 st = starts;
@@ -424,10 +438,10 @@ __global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatt
                     const u32 coarse = (u32)(((u64)slot * smagic) >> 40), fine = slot - coarse * S;
                     for (u32 s2 = s; len; ) {
                         const u32 n = len < nmax ? len : nmax;
-                        const u64 lo = ((u64)cw[1] << 32) | cw[0], hi = ((u64)cw[3] << 32) | cw[2];
+                        const u64 w0 = ((u64)cw[1] << 32) | cw[0], w1 = ((u64)cw[3] << 32) | cw[2], w2 = ((u64)cw[5] << 32) | cw[4];
                         const u32 sh = 2 * s2;
-                        u64 rlo = sh ? (lo >> sh) | ((hi << 1) << (63 - sh)) : lo;
-                        u64 rhi = hi >> sh;
+                        u64 rlo = sh ? (w0 >> sh) | ((w1 << 1) << (63 - sh)) : w0;
+                        u64 rhi = sh ? (w1 >> sh) | ((w2 << 1) << (63 - sh)) : w1;
                         const u32 bits = 2 * (n + (u32)k - 1);
                         if (bits < 64) { rlo &= (1ull << bits) - 1ull; rhi = 0; }
                         else rhi &= kh_mask((int)bits - 64);
