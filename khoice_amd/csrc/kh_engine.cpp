@@ -1566,9 +1566,10 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     const u32 nslots = (u32)nslots64;
     const u32 S = std::max<u32>(1, (nslots + KH_SKM_MAX_COARSE - 1) / KH_SKM_MAX_COARSE);
     const u32 nb1 = (nslots + S - 1) / S;
-    // records: a run of k-mers with one minimizer is w/2 + 1/2 long on average and is cut at every
-    // 32-position thread boundary and at nmax
-    const double per_kmer = 1.0 / 32.0 + 2.0 / (double)(w + 1) + 1.0 / (double)nmax;
+    // records: a run of k-mers with one minimizer is (w + 1) / 2 long on average; cuts at the waves' 2048
+    // positions, at boundaries a run may not cross (a second thread boundary, nmax) and at invalid bases add
+    // a little (measured: 0.120 records per k-mer at w = 16, 0.27 at w = 7)
+    const double per_kmer = 2.0 / (double)(w + 1) + 1.0 / 48.0;
     const double recs = (double)total_pos * per_kmer;
     double slack1 = 1.25, slack2 = 1.7;
     if (const char* e = getenv("KHOICE_SKM_SLACK")) slack1 = slack2 = std::max(0.01, atof(e));   // below 1: tests of the overflow fall-back
