@@ -23,8 +23,8 @@ BINDIR = os.path.join(ROOT, "bin")
 LIB = os.path.join(LIBDIR, "libkhoice_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["kh_kernels.hip", "kh_skm.hip", "kh_ingest.hip", "kh_engine.cpp", "kh_io.cpp", "kh_comm.cpp"]
-HEADERS = ["kh_common.h", "kh_device.h", "kh_launch.h", "kh_engine.h", os.path.join(ROOT, "include", "khoice_hip.h")]
+HIP_SOURCES = ["kh_kernels.hip", "kh_skm.hip", "kh_skm2.hip", "kh_ingest.hip", "kh_engine.cpp", "kh_io.cpp", "kh_comm.cpp"]
+HEADERS = ["kh_common.h", "kh_device.h", "kh_skm_device.h", "kh_launch.h", "kh_engine.h", os.path.join(ROOT, "include", "khoice_hip.h")]
 CLIS = {"kmc": "kmc_main.cpp", "kmc_tools": "kmc_tools_main.cpp", "khoice_server": "kh_server_main.cpp"}
 CLI_COMMON = "kh_cli.cpp"
 

@@ -1526,7 +1526,9 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
                     const int* group_of, int ngroups, int k, u32 cs, uint64_t* within_hist,
                     uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, bool* done) {
     *done = false;
-    if (k < KH_SKM_MIN_K || k > KH_SKM_MAX_K || getenv("KHOICE_NO_SKM")) return KH_OK;
+    if (k < KH_SKM_MIN_K || k > KH_SKM2_MAX_K || getenv("KHOICE_NO_SKM")) return KH_OK;
+    const bool two = k > KH_SKM_MAX_K;   // two-word keys: 32-byte records, kh_skm2.hip
+    if (two && getenv("KHOICE_NO_SKM2")) return KH_OK;
     if (nseq > KH_TAG_MAX_OPS || ngroups > KH_TAG_MAX_OPS) return KH_OK;
     std::vector<int> gsize(ngroups, 0), gstart(ngroups + 1, 0), perm(nseq);
     for (int i = 0; i < nseq; ++i) gsize[group_of[i]]++;
@@ -1546,25 +1548,47 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         for (int i = 0; i < nseq; ++i) perm[at[group_of[i]]++] = i;
     }
     // ---- geometry: minimizer length, slots, regions
-    const int m15w = k - 15 + 1;                                   // m-mers per k-mer with m = 15
-    int m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;   // m = 16 when that makes w a power of two
-    if (const char* e = getenv("KHOICE_SKM_M")) m = std::min(16, std::max(2, atoi(e)));   // experiments
-    if (m >= k) return KH_OK;
-    const u32 w = (u32)(k - m + 1);
-    const u32 nmax = (u32)std::min(31, 55 - k);
-    if (!kh_skm_supports_w(w)) return KH_OK;
+    int m;
+    u32 w, nmax;
+    if (!two) {
+        const int m15w = k - 15 + 1;                                   // m-mers per k-mer with m = 15
+        m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;   // m = 16 when that makes w a power of two
+        if (const char* e = getenv("KHOICE_SKM_M")) m = std::min(16, std::max(2, atoi(e)));   // experiments
+        if (m >= k) return KH_OK;
+        w = (u32)(k - m + 1);
+        nmax = (u32)std::min(31, 55 - k);
+        if (!kh_skm_supports_w(w)) return KH_OK;
+    } else {   // the scatter exists for every third window width: one of m = 16, 15, 14 fits
+        m = 16;
+        while (m >= 14 && !kh_skm2_supports_w((u32)(k - m + 1))) --m;
+        if (m < 14) return KH_OK;
+        w = (u32)(k - m + 1);
+        nmax = (u32)std::min(63, 118 - k);
+    }
     u64 total_pos = 0, bases = 0, seq_bytes = 0;
     for (int i = 0; i < nseq; ++i) {
         total_pos += lens[i] >= (u64)k ? lens[i] - k + 1 : 0;
         bases += lens[i];
     }
     if (!total_pos) return KH_OK;
-    u32 mean = 3200;   // k-mer instances per slot (hash set of 4096 entries; measured 2500 / 2900 / 3200 / 3500 / 3800: 1.96 / 1.81 / 1.75 / 1.80 / 1.94 ms)
+    // k-mer instances per slot: the hash set takes T = 4096 (2048 for two-word keys) per round.  The genomes of a
+    // group put their copies of a locus in the same slot, a minimizer run at a time: clumps of c = (w + 1) / 2 x
+    // (largest group) instances, so sigma = sqrt(mean x c); mean + 2.5 sigma = T  (measured: 2500 / 2900 / 3200 /
+    // 3500 / 3800 at k = 31 with groups of five: union 1.96 / 1.81 / 1.75 / 1.80 / 1.94 ms; the rule gives 3180)
+    u32 mean;
+    {
+        u32 fan = 1;
+        for (int g = 0; g < ngroups; ++g) fan = std::max<u32>(fan, (u32)gsize[g]);
+        const double T = two ? (double)kh_skm2_table() : 4096.0, cl = 0.5 * (double)(w + 1) * (double)fan;
+        const double r = 0.5 * (-2.5 * std::sqrt(cl) + std::sqrt(6.25 * cl + 4.0 * T));
+        mean = (u32)std::max(256.0, r * r);
+    }
     if (const char* e = getenv("KHOICE_SKM_MEAN")) mean = std::max<u32>(64, (u32)strtoul(e, nullptr, 10));
     const u64 nslots64 = std::max<u64>(1, (total_pos + mean - 1) / mean);
-    if (nslots64 > (u64)KH_SKM_MAX_COARSE * KH_SKM_MAX_FINE) return KH_OK;
+    const u32 max_coarse = two ? KH_SKM2_MAX_COARSE : KH_SKM_MAX_COARSE;
+    if (nslots64 > (u64)max_coarse * KH_SKM_MAX_FINE) return KH_OK;
     const u32 nslots = (u32)nslots64;
-    const u32 S = std::max<u32>(1, (nslots + KH_SKM_MAX_COARSE - 1) / KH_SKM_MAX_COARSE);
+    const u32 S = std::max<u32>(1, (nslots + max_coarse - 1) / max_coarse);
     const u32 nb1 = (nslots + S - 1) / S;
     // records: a run of k-mers with one minimizer is (w + 1) / 2 long on average; cuts at the waves' 2048
     // positions, at boundaries a run may not cross (a second thread boundary, nmax) and at invalid bases add
@@ -1575,9 +1599,10 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     if (const char* e = getenv("KHOICE_SKM_SLACK")) slack1 = slack2 = std::max(0.01, atof(e));   // below 1: tests of the overflow fall-back
     const u64 cap1_64 = ((u64)(recs / nb1 * slack1) + 2048 + 63) & ~63ull;
     const u64 cap2_64 = ((u64)(recs / nslots * slack2) + 96 + 15) & ~15ull;
-    if (cap2_64 > KH_SKM_MAX_CAP2 || cap1_64 > 0x7fffffffull) return KH_OK;
+    if (cap2_64 > (two ? kh_skm2_max_cap2() : KH_SKM_MAX_CAP2) || cap1_64 > 0x7fffffffull) return KH_OK;
     const u32 cap1 = (u32)cap1_64, cap2 = (u32)cap2_64;
-    const size_t reg1_bytes = 16 * (size_t)nb1 * cap1, reg2_bytes = 16 * (size_t)nslots * cap2;
+    const size_t rec_bytes = two ? 32 : 16;
+    const size_t reg1_bytes = rec_bytes * (size_t)nb1 * cap1, reg2_bytes = rec_bytes * (size_t)nslots * cap2;
     HIPCHK(hipSetDevice(c->dev));
     {
         size_t free_b = 0, total_b = 0;
@@ -1683,7 +1708,8 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     kh_debug_set_stamps_skm(d_stamps.as<u64>());
 #endif
     c->prof_begin(KC_SKM_SCATTER);
-    kh_launch_skm_scatter(job, ntiles, st);
+    if (two) kh_launch_skm2_scatter(job, ntiles, st);
+    else kh_launch_skm_scatter(job, ntiles, st);
     c->prof_end();
 #ifdef KH_STAMPS
     report_stamps(c, "skm_scatter (second sub-tile: codes / hashes / minima / slots+count / - / append / barrier / -)", d_stamps.b, ntiles);
@@ -1691,13 +1717,15 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     kh_debug_set_stamps_skm(nullptr);
 #endif
     c->prof_begin(KC_SKM_REGROUP);
-    kh_launch_skm_regroup(job, st);
+    if (two) kh_launch_skm2_regroup(job, st);
+    else kh_launch_skm_regroup(job, st);
     c->prof_end();
 #ifdef KH_STAMPS
     kh_debug_set_stamps_skm(d_stamps.as<u64>());
 #endif
     c->prof_begin(KC_SKM_UNION);
-    kh_launch_skm_union(job, cs, st);
+    if (two) kh_launch_skm2_union(job, cs, st);
+    else kh_launch_skm_union(job, cs, st);
     c->prof_end();
     HIPCHK(hipGetLastError());
 #ifdef KH_STAMPS

@@ -158,6 +158,18 @@ size_t kh_skm_union_lds_bytes(u32 nbins);
 void kh_launch_skm_scatter(const KhSkmJob& job, u32 ntiles, hipStream_t st);
 void kh_launch_skm_regroup(const KhSkmJob& job, hipStream_t st);
 void kh_launch_skm_union(const KhSkmJob& job, u32 cs, hipStream_t st);
+// the same three steps for two-word keys (kh_skm2.hip): 32-byte records (two uint4 per record in reg1 / reg2)
+constexpr int KH_SKM2_MAX_K = 63;         // k = 64: the all-ones low key word is a k-mer (A^32 T^32)
+constexpr u32 KH_SKM2_MAX_COARSE = 512;
+bool kh_skm2_supports_w(u32 w);
+u32 kh_skm2_max_cap2();
+u32 kh_skm2_table();
+size_t kh_skm2_scatter_lds_bytes(u32 nb1);
+size_t kh_skm2_regroup_lds_bytes(u32 S);
+size_t kh_skm2_union_lds_bytes(u32 nbins);
+void kh_launch_skm2_scatter(const KhSkmJob& job, u32 ntiles, hipStream_t st);
+void kh_launch_skm2_regroup(const KhSkmJob& job, hipStream_t st);
+void kh_launch_skm2_union(const KhSkmJob& job, u32 cs, hipStream_t st);
 
 struct KhLookback {      // workspace of one ordered single-pass launch
     u64* desc;           // [nparts] tile descriptors, zeroed before launch

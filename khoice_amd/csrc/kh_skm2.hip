@@ -1,0 +1,599 @@
+// khoice_amd — the super-k-mer form of the fused experiment-type-1 path for TWO-WORD keys (33 <= k <= 63).
+//
+// Same three steps as kh_skm.hip (which see: minimizer records, two LDS counting-sort levels, one LDS hash
+// set per slot), with what 2k > 64 bits changes:
+//   * a record is 32 bytes: bits [0, 2(n+k-1)) the bases, in the last word n (6 bits, 26..31), the genome
+//     number (20..25), the fine slot index (11..19); n <= min(63, 118 - k);
+//   * a k-mer has up to 49 m-mers: the sliding minimum needs the hashes of the NEXT TWO threads (two DPP
+//     wave_shl steps) and 96 validity flags per thread;
+//   * the hash set cannot claim a 128-bit key with one compare-and-swap.  An entry is claimed on the LOW word
+//     (compare-and-swap against the empty marker); the winner then stores the high word and sets the entry's
+//     ready byte (LDS operations of one wave are performed in order).  A key that finds its own low word in an
+//     entry waits for the ready byte and compares the high word: equal — its entry; different — another key
+//     (same low word: as good as never), on to the next entry.  In every round the owners publish before the
+//     readers of the same wave look, so a wave never waits for itself; other waves run on without barriers.
+//     The all-ones low word cannot be canonical for k <= 63 (a k-mer that ends in 32 T has a reverse
+//     complement below 2^62), so it stays the empty marker; k = 64 takes the key-array form.
+#include <hip/hip_runtime.h>
+
+#include "kh_device.h"
+#include "kh_launch.h"
+
+#define SKM_STAMP(idx) do {} while (0)   // (the phase stamps live in kh_skm.hip's kernels only)
+#include "kh_skm_device.h"
+
+namespace {
+
+constexpr u32 SKM2_CAP = 768;                   // 32-byte records staged per flush of the scatter
+constexpr u32 SKM2_RG_CAP = 4096;               // records per round of the regroup
+constexpr u32 SKM2_CWN = 10;                    // code words a thread keeps: bases p .. p + 159
+
+__device__ __forceinline__ u32 rec2_n(u32 w7) { return w7 >> 26; }
+__device__ __forceinline__ u32 rec2_tag(u32 w7) { return (w7 >> 20) & 63u; }
+__device__ __forceinline__ u32 rec2_fine(u32 w7) { return (w7 >> 11) & 511u; }
+
+}   // namespace
+
+size_t kh_skm2_scatter_lds_bytes(u32 nb1) {
+    const u32 nbk = (nb1 + 3) & ~3u;
+    return flush_lds_bytes<SKM2_CAP, 8>(nbk) + (size_t)SKM_CW * 4 + (((size_t)SKM_CW * 2 + 15) & ~(size_t)15) + 64 * 4 + 4 * 64 * 4 + 64;
+}
+size_t kh_skm2_regroup_lds_bytes(u32 S) { return flush_lds_bytes<SKM2_RG_CAP, 8>((S + 3) & ~3u) + (size_t)((S + 3) & ~3u) * 4 + 64; }
+
+// ------------------------------------------------------------------------------------------
+// S1: bases -> 32-byte records, partitioned by coarse bucket.  WW = m-mers per k-mer, compile time.
+// ------------------------------------------------------------------------------------------
+template <int WW>
+__global__ __launch_bounds__(SKM_NT, 2) void k_skm2_scatter(const KhSkmJob jb) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    const u32 nbk = (jb.nb1 + 3) & ~3u;
+    const FlushLds L = flush_lds<SKM2_CAP, 8>(lds_raw, nbk);
+    u8* p = lds_raw + flush_lds_bytes<SKM2_CAP, 8>(nbk);
+    u32* code = reinterpret_cast<u32*>(p);                    p += (size_t)SKM_CW * 4;
+    u16* bad16 = reinterpret_cast<u16*>(p);                   p += ((size_t)SKM_CW * 2 + 15) & ~(size_t)15;
+    u32* tailh = reinterpret_cast<u32*>(p);                   p += 64 * 4;       // hashes of positions SUB .. SUB + 63
+    u32* xch = reinterpret_cast<u32*>(p);                     p += 4 * 64 * 4;   // [wave][j]: hashes of the wave's first 64 positions
+    u32* misc = reinterpret_cast<u32*>(p);                    // [1] valid k-mers of the tile, [2] scratch, [4..] scan scratch
+
+    const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const KhTile t = jb.tiles[blockIdx.x];
+    const KhSeg sg = jb.segs[t.seg];
+    const int k = jb.k, m = jb.m;
+    const u32 nslots = jb.nslots, S = jb.S, nmax = jb.nmax;
+    const u64 smagic = ((1ull << 40) + S - 1) / S;   // slot / S == (slot * smagic) >> 40 for slot < 2^20
+    const u32 mmask = m >= 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+    const u64 tile_pos0 = (u64)t.tile_in_seg * jb.tile_pos;
+    const int subtiles = (int)(jb.tile_pos / SKM_SUB);
+
+    for (u32 i = tid; i < nbk; i += SKM_NT) L.bcnt[i] = 0;
+    if (tid < 4) misc[tid] = 0;
+    u32 staged = 0, tile_recs = 0;   // uniform
+
+    SkmFetch pre;
+    skm_fetch(sg.seq, sg.len, tile_pos0, pre);
+    for (int sub = 0; sub < subtiles; ++sub) {
+        const u64 p0 = tile_pos0 + (u64)sub * SKM_SUB;
+        if (p0 >= sg.npos) break;   // uniform
+        __syncthreads();
+        skm_store(pre, code, bad16);
+        __syncthreads();
+        if (sub + 1 < subtiles && p0 + SKM_SUB < sg.npos) skm_fetch(sg.seq, sg.len, p0 + SKM_SUB, pre);
+        // ---- hashes of the m-mers starting at the thread's 32 positions
+        u32 cw[SKM2_CWN];   // (the last threads' words past the sub-tile's halo are never part of a record: clamped)
+#pragma unroll
+        for (int i = 0; i < (int)SKM2_CWN; ++i) cw[i] = code[2 * tid + i < SKM_CW ? 2 * tid + i : SKM_CW - 1];
+        u32 cur[SKM_PPT + WW - 1];
+        {
+            const u32 pm = (u32)(m - 1);
+            const u32 pre_w = cw[0] & ((1u << (2 * pm)) - 1u);
+            u32 f = revpairs32(pre_w) >> (32 - 2 * pm);
+            u32 r = ((~pre_w) & ((1u << (2 * pm)) - 1u)) << 2;
+            u32 nw[2];
+            nw[0] = __builtin_amdgcn_alignbit(cw[1], cw[0], 2 * pm);
+            nw[1] = __builtin_amdgcn_alignbit(cw[2], cw[1], 2 * pm);
+#pragma unroll
+            for (int j = 0; j < (int)SKM_PPT; ++j) {
+                const u32 c = (nw[j >> 4] >> (2 * (j & 15))) & 3u;
+                f = ((f << 2) | c) & mmask;
+                r = (r >> 2) | ((3u - c) << (2 * pm));
+                cur[j] = mmer_hash(f < r ? f : r);
+            }
+        }
+        {
+            if (tid < 64) {   // positions SUB .. SUB + 63, straight from the packed window
+                const u32 q = SKM_SUB + tid, wq = q >> 4, oq = q & 15u;
+                const u32 x = __builtin_amdgcn_alignbit(code[wq + 1], code[wq], 2 * oq) & mmask;
+                const u32 f = revpairs32(x) >> (32 - 2 * m);
+                const u32 r = (~x) & mmask;
+                tailh[tid] = mmer_hash(f < r ? f : r);
+            }
+            if (lane < 2) {
+#pragma unroll
+                for (int j = 0; j < (int)SKM_PPT; ++j) xch[wid * 64 + lane * SKM_PPT + (u32)j] = cur[j];
+            }
+            __syncthreads();
+            // the WW - 1 hashes behind the thread's own: the next thread's 32, then the one after's
+            const u32* nx = wid + 1 < SKM_NT / 64 ? xch + (wid + 1) * 64 : tailh;
+            constexpr int H1 = WW - 1 < (int)SKM_PPT ? WW - 1 : (int)SKM_PPT;
+#pragma unroll
+            for (int j = 0; j < H1; ++j) cur[SKM_PPT + j] = next_lane(cur[j], lane == KH_WAVE - 1 ? nx[j] : 0u);
+#pragma unroll
+            for (int j = 0; j < WW - 1 - H1; ++j)
+                cur[2 * SKM_PPT + j] = next_lane(cur[SKM_PPT + j], lane == KH_WAVE - 1 ? nx[SKM_PPT + j] : 0u);
+            window_min<WW>(cur);
+        }
+        // ---- which of the 32 start positions have k valid bases (96 flags)
+        u32 vm;
+        {
+            u64 lo = (u64)bad16[2 * tid] | ((u64)bad16[2 * tid + 1] << 16) | ((u64)bad16[2 * tid + 2] << 32) |
+                     ((u64)bad16[2 * tid + 3] << 48);
+            const u32 i4 = 2 * tid + 4 < SKM_CW ? 2 * tid + 4 : SKM_CW - 1, i5 = 2 * tid + 5 < SKM_CW ? 2 * tid + 5 : SKM_CW - 1;
+            u64 hi = (u64)bad16[i4] | ((u64)bad16[i5] << 16);
+            auto shr_or = [&](u32 c) {   // (hi:lo) |= (hi:lo) >> c, 0 < c < 64
+                const u64 nlo = (lo >> c) | ((hi << 1) << (63 - c)), nhi = hi >> c;
+                lo |= nlo;
+                hi |= nhi;
+            };
+            u32 cover = 1;
+            while (2 * cover <= (u32)k) { shr_or(cover); cover <<= 1; }
+            if ((u32)k > cover) shr_or((u32)k - cover);
+            vm = ~(u32)lo;
+        }
+        // ---- runs of valid positions with one minimizer become records (see kh_skm.hip)
+        u32 sl[SKM_PPT];
+        u32 cont = 0;
+#pragma unroll
+        for (int j = 0; j < (int)SKM_PPT; ++j) {
+            sl[j] = cur[j];
+            if (j && cur[j] == cur[j - 1]) cont |= 1u << j;
+        }
+        cont &= vm & (vm << 1);
+        const u32 tr = (vm >> 31) ? 1u + (u32)__builtin_clz(~cont | 1u) : 0u;
+        const u32 lead = 1u + (u32)__builtin_ctz(~(cont >> 1));
+        const u32 p_min = (u32)__builtin_amdgcn_update_dpp(0, (int)cur[SKM_PPT - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
+        const u32 p_tr = (u32)__builtin_amdgcn_update_dpp(0, (int)tr, 0x138, 0xf, 0xf, false);
+        // (a run goes over ONE thread boundary at most: the previous thread's last run must start inside it, and
+        // mine must end inside me)
+        const bool merge_in = lane != 0 && p_tr != 0 && p_tr < SKM_PPT && lead < SKM_PPT && (vm & 1u) && p_min == cur[0] &&
+                              p_tr + lead <= nmax;
+        const u32 ext = next_lane(merge_in ? lead : 0u, 0u);
+        const u32 starts = (vm & ~cont) & ~(merge_in ? 1u : 0u);
+        auto run_len = [&](u32 s) -> u32 {
+            const u32 len = 1u + (u32)__builtin_ctzll(~((u64)cont >> (s + 1)));
+            return s + len == SKM_PPT ? len + ext : len;
+        };
+        u32 nrec = 0;
+        {
+            u32 st = starts;
+            while (st) {
+                const u32 s = (u32)__builtin_ctz(st);
+                st &= st - 1;
+                const u32 len = run_len(s);
+                nrec += (len + nmax - 1) / nmax;
+            }
+        }
+        {   // valid k-mer instances of the tile
+            const u32 tot = wave_scan_add((u32)__popc(vm));
+            if (lane == KH_WAVE - 1 && tot) atomicAdd(&misc[1], tot);
+        }
+        // ---- append to the staging array; a full array is flushed (a prefix of the threads fits)
+        bool done = false, first_round = true;
+        while (true) {
+            const u32 mine = done ? 0u : nrec;
+            const u32 incl = wave_scan_add(mine);
+            if (lane == KH_WAVE - 1) misc[4 + wid] = incl;
+            __syncthreads();
+            u32 excl = incl - mine, total = 0;
+            for (u32 q = 0; q < SKM_NT / 64; ++q) {
+                const u32 v = misc[4 + q];
+                excl += q < wid ? v : 0u;
+                total += v;
+            }
+            if (first_round) { tile_recs += total; first_round = false; }
+            const bool fits = staged + excl + mine <= SKM2_CAP;
+            if (!done && fits) {
+                u32 at = staged + excl;
+                u32 st = starts;
+                while (st) {
+                    const u32 s = (u32)__builtin_ctz(st);
+                    st &= st - 1;
+                    u32 len = run_len(s);
+                    const u32 slot = slot_of(pick32(sl, s), nslots);
+                    const u32 coarse = (u32)(((u64)slot * smagic) >> 40), fine = slot - coarse * S;
+                    for (u32 s2 = s; len; ) {
+                        const u32 n = len < nmax ? len : nmax;
+                        const u32 sh = 2 * s2, r5 = sh & 31u;
+                        const bool up = sh >= 32;
+                        u32 src[9], out[8];
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) src[i] = up ? cw[i + 1] : cw[i];
+                        const u32 bits = 2 * (n + (u32)k - 1);   // <= 236
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const u32 wv = __builtin_amdgcn_alignbit(src[i + 1], src[i], r5);
+                            out[i] = bits >= 32u * (i + 1) ? wv : (bits > 32u * i ? wv & ((1u << (bits - 32u * i)) - 1u) : 0u);
+                        }
+                        out[7] |= (fine << 11) | (t.seg << 20) | (n << 26);
+                        L.stage[2 * at] = make_uint4(out[0], out[1], out[2], out[3]);
+                        L.stage[2 * at + 1] = make_uint4(out[4], out[5], out[6], out[7]);
+                        L.sid[at] = (u16)coarse;
+                        atomicAdd(&L.bcnt[coarse], 1u);
+                        ++at;
+                        s2 += n;
+                        len -= n;
+                    }
+                }
+                done = true;
+            }
+            const u32 room = SKM2_CAP - staged;
+            if (total <= room) {   // all fitted: the common case
+                staged += total;
+                __syncthreads();
+                break;
+            }
+            if (tid == 0) misc[2] = 0;
+            __syncthreads();
+            if (fits && mine) atomicMax(&misc[2], excl + mine);
+            __syncthreads();
+            const u32 part = misc[2];
+            skm_flush<SKM_NT, SKM2_CAP, false, 8>(L, staged + part, jb.nb1, jb.cur1, jb.reg1, jb.cap1, jb.ctl);
+            staged = 0;
+        }
+    }
+    __syncthreads();
+    if (staged) skm_flush<SKM_NT, SKM2_CAP, false, 8>(L, staged, jb.nb1, jb.cur1, jb.reg1, jb.cap1, jb.ctl);
+    if (tid == 0 && misc[1]) atomicAdd(&jb.inst[t.seg], (unsigned long long)misc[1]);
+    if (tid == 0 && tile_recs) atomicAdd(jb.ctl + 2, tile_recs);
+}
+
+// ------------------------------------------------------------------------------------------
+// S2a: one workgroup per coarse bucket, 4096 records per round, regrouped by fine slot (cursors in LDS)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm2_regroup(const KhSkmJob jb) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    constexpr int RPT = (int)(SKM2_RG_CAP / SKM_RG_NT);
+    const u32 nbk = (jb.S + 3) & ~3u;
+    const FlushLds L = flush_lds<SKM2_RG_CAP, 8>(lds_raw, nbk);
+    u32* lcur = reinterpret_cast<u32*>(lds_raw + flush_lds_bytes<SKM2_RG_CAP, 8>(nbk));   // [nbk] records written per slot
+    const u32 tid = threadIdx.x;
+    const u32 b = blockIdx.x;
+    const u32 have = jb.cur1[(size_t)b * KH_SKM_CUR1_STRIDE];
+    const u32 cnt = have < jb.cap1 ? have : jb.cap1;
+    const u32 first_slot = b * jb.S;
+    const u32 nfine = jb.nslots - first_slot < jb.S ? jb.nslots - first_slot : jb.S;
+    for (u32 i = tid; i < nbk; i += SKM_RG_NT) { L.bcnt[i] = 0; lcur[i] = 0; }
+    const uint4* __restrict__ src = jb.reg1 + (u64)b * jb.cap1 * 2;
+    uint4* __restrict__ dst = jb.reg2 + (u64)first_slot * jb.cap2 * 2;
+    uint4 nx[RPT][2];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const u32 i = tid + (u32)r * SKM_RG_NT;
+        nx[r][0] = i < cnt ? src[2 * i] : make_uint4(0, 0, 0, 0);
+        nx[r][1] = i < cnt ? src[2 * i + 1] : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (u32 start = 0; start < cnt; start += SKM2_RG_CAP) {
+        const u32 n = cnt - start < SKM2_RG_CAP ? cnt - start : SKM2_RG_CAP;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const u32 i = tid + (u32)r * SKM_RG_NT;
+            if (i < n) {
+                u32 fine = rec2_fine(nx[r][1].w);
+                if (fine >= nfine) { fine = 0; atomicOr(jb.ctl, KH_ERR_ORDER); }   // a corrupt record never leaves its bucket
+                L.stage[2 * i] = nx[r][0];
+                L.stage[2 * i + 1] = nx[r][1];
+                L.sid[i] = (u16)fine;
+                atomicAdd(&L.bcnt[fine], 1u);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {   // the next round's records: in flight during the flush
+            const u32 i = start + SKM2_RG_CAP + tid + (u32)r * SKM_RG_NT;
+            nx[r][0] = i < cnt ? src[2 * i] : make_uint4(0, 0, 0, 0);
+            nx[r][1] = i < cnt ? src[2 * i + 1] : make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        skm_flush<SKM_RG_NT, SKM2_RG_CAP, true, 8>(L, n, nfine, lcur, dst, jb.cap2, jb.ctl);
+    }
+    for (u32 i = tid; i < nfine; i += SKM_RG_NT) jb.cur2[first_slot + i] = lcur[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// S2b: one slot per workgroup -> LDS hash set {128-bit canonical k-mer, genome mask} -> histogram bins
+// ------------------------------------------------------------------------------------------
+#ifndef KH_TUNE_SKM2_UNT
+#define KH_TUNE_SKM2_UNT 1024   // two workgroups per CU = 8 waves per SIMD (512: 5.0 ms against 3.5 at k = 41)
+#endif
+constexpr u32 SKM2_UNT = KH_TUNE_SKM2_UNT, SKM2_UT = 2048, SKM2_UE = SKM2_UT / SKM2_UNT, SKM2_UT2 = 128;
+constexpr u32 SKM2_UNW = SKM2_UNT / 64;
+constexpr u32 SKM2_URPT = 1024 / SKM2_UNT;         // records per thread when the slot is read: cap2 <= 1024
+constexpr u32 SKM2_SPEC = 320;                     // records of a slot read before their number is known
+constexpr u32 SKM2_OWN = 2048;                     // chunk owners: a slot of up to SKM2_UE * 2048 k-mer instances
+size_t kh_skm2_union_lds_bytes(u32 nbins) {
+    return (size_t)SKM2_UT * 25 + (size_t)SKM2_UT2 * 25 + 128 + 256 + 128 + 256 + (((size_t)nbins * 32 + 15) & ~(size_t)15) +
+           (size_t)(SKM2_URPT * SKM2_UNT + 8) * 2 + (size_t)SKM2_OWN * 2;
+}
+u32 kh_skm2_max_cap2() { return SKM2_URPT * SKM2_UNT; }
+u32 kh_skm2_table() { return SKM2_UT; }
+
+__global__ __launch_bounds__(SKM2_UNT, 2 * (SKM2_UNT / 64) / 4) void k_skm2_union(const KhSkmJob jb, u32 cs) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    constexpr u32 NT = SKM2_UNT, T = SKM2_UT, T2 = SKM2_UT2, HBITS = 11;
+    constexpr int E = (int)SKM2_UE;
+    constexpr u64 EMPTY = ~0ull;   // never the low word of a canonical key for k <= 63 (see the head of the file)
+    struct Tbl { unsigned long long* klo; unsigned long long* khi; u32* mlo; u32* mhi; u8* rdy; };
+    u8* p = lds_raw;
+    Tbl tbl, ovf;
+    tbl.klo = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T * 8;
+    tbl.khi = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T * 8;
+    tbl.mlo = reinterpret_cast<u32*>(p);                      p += (size_t)T * 4;
+    tbl.mhi = reinterpret_cast<u32*>(p);                      p += (size_t)T * 4;
+    tbl.rdy = p;                                              p += (size_t)T;
+    ovf.klo = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T2 * 8;
+    ovf.khi = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T2 * 8;
+    ovf.mlo = reinterpret_cast<u32*>(p);                      p += (size_t)T2 * 4;
+    ovf.mhi = reinterpret_cast<u32*>(p);                      p += (size_t)T2 * 4;
+    ovf.rdy = p;                                              p += (size_t)T2 + 128;
+    u32* ginfo = reinterpret_cast<u32*>(p);                   p += 256;
+    u32* scratch = reinterpret_cast<u32*>(p);                 p += 128;
+    u32* dupc = reinterpret_cast<u32*>(p);                    p += 256;
+    u32* hstripe = reinterpret_cast<u32*>(p);                 p += ((size_t)jb.nbins * 32 + 15) & ~(size_t)15;
+    u16* roff = reinterpret_cast<u16*>(p);                    p += (size_t)(SKM2_URPT * NT + 8) * 2;
+    u16* owner = reinterpret_cast<u16*>(p);
+    const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const u32 nbins = jb.nbins, cap2 = jb.cap2;
+    const int k = jb.k;
+    const u32 slot = blockIdx.x;
+    const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2 * 2;
+    // ---- the k-mer counts of the slot's records (the last word of each), SKM2_URPT consecutive records per thread
+    const u32 have = jb.cur2[slot];
+    u32 top[SKM2_URPT];
+#pragma unroll
+    for (u32 j = 0; j < SKM2_URPT; ++j) {
+        const u32 i = SKM2_URPT * tid + j;
+        top[j] = i < (cap2 < SKM2_SPEC ? cap2 : SKM2_SPEC) ? reg[2 * i + 1].w : 0u;
+    }
+    auto clear_tables = [&]() {
+        for (u32 i = tid; i < T; i += NT) { tbl.klo[i] = EMPTY; tbl.mlo[i] = 0u; tbl.mhi[i] = 0u; tbl.rdy[i] = 0; }
+        for (u32 i = tid; i < T2; i += NT) { ovf.klo[i] = EMPTY; ovf.mlo[i] = 0u; ovf.mhi[i] = 0u; ovf.rdy[i] = 0; }
+    };
+    for (u32 i = tid; i < (u32)KH_TAG_MAX_OPS; i += NT) { ginfo[i] = jb.ginfo[i]; dupc[i] = 0; }
+    for (u32 i = tid; i < nbins * 8u; i += NT) hstripe[i] = 0;
+    clear_tables();
+    const u32 nrec = have < cap2 ? have : cap2;
+    if (nrec > SKM2_SPEC) {   // uniform, rare
+#pragma unroll
+        for (u32 j = 0; j < SKM2_URPT; ++j) {
+            const u32 i = SKM2_URPT * tid + j;
+            if (i >= SKM2_SPEC && i < nrec) top[j] = reg[2 * i + 1].w;
+        }
+    }
+    u32 nj[SKM2_URPT], mine = 0;
+#pragma unroll
+    for (u32 j = 0; j < SKM2_URPT; ++j) {
+        nj[j] = SKM2_URPT * tid + j < nrec ? rec2_n(top[j]) : 0u;
+        mine += nj[j];
+    }
+    const u32 incl = wave_scan_add(mine);
+    if (lane == KH_WAVE - 1) scratch[wid] = incl;
+    __syncthreads();
+    u32 off = incl - mine, N = 0;
+    for (u32 q = 0; q < SKM2_UNW; ++q) {
+        const u32 v = scratch[q];
+        off += q < wid ? v : 0u;
+        N += v;
+    }
+    if (tid == 0 && N > T) atomicMax(jb.ctl + 1, N);
+    if (N > (u32)E * SKM2_OWN) {   // uniform: a slot this full goes back to the host
+        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+        N = 0;
+    }
+    if (N) {
+#pragma unroll
+        for (u32 j = 0; j < SKM2_URPT; ++j) {
+            if (nj[j]) {
+                roff[SKM2_URPT * tid + j] = (u16)off;
+                for (u32 c = (off + (u32)E - 1) / (u32)E; c <= (off + nj[j] - 1) / (u32)E; ++c) owner[c] = (u16)(SKM2_URPT * tid + j);
+                off += nj[j];
+            }
+        }
+    }
+    __syncthreads();
+    const u32 R = (N + T - 1) / T;   // key subsets handled one after the other (1 unless the slot is overfull)
+    // the 2k-bit mask and the shift that right-aligns a reversed 128-bit window, as 32-bit words (uniform)
+    const u32 kb = 2 * (u32)k;          // 66 .. 126
+    u32 km[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) km[i] = kb >= 32u * (i + 1) ? 0xffffffffu : (kb > 32u * i ? (1u << (kb - 32u * i)) - 1u : 0u);
+    const u32 fs = 128u - kb;           // 2 .. 62
+    auto eval_mask = [&](u64 mask, u32 g) -> u32 {
+        u32 ng = 0;
+        while (true) {
+            const u32 g0 = g & 0xffu, gn = (g >> 8) & 0xffu, bin0 = g >> 16;
+            const u64 gm = (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0;
+            u32 c = (u32)__popcll(mask & gm);
+            c = c < cs ? c : cs;
+            atomicAdd(&hstripe[(bin0 + c) * 8u + (lane & 7u)], 1u);
+            mask &= ~gm;
+            ++ng;
+            if (!mask) break;
+            g = ginfo[__ffsll((unsigned long long)mask) - 1];
+        }
+        return ng < cs ? ng : cs;
+    };
+    for (u32 q = 0; q < R; ++q) {
+        if (q) { clear_tables(); __syncthreads(); }
+        for (u32 base = 0; base < N; base += NT * (u32)E) {
+            const u32 j0 = base + (u32)E * tid;
+            u64 klo[E], khi[E];
+            u32 tagp = 0, slot_[E], act = 0;
+            if (j0 < N) {
+                u32 ri = owner[j0 / (u32)E];
+                u32 o = j0 - roff[ri];
+                uint4 a = reg[2 * ri], b = reg[2 * ri + 1];
+                u32 cn = rec2_n(b.w), ctag = rec2_tag(b.w);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    klo[e] = EMPTY;
+                    khi[e] = 0;
+                    slot_[e] = 0;
+                    if (j0 + (u32)e < N) {
+                        if (o == cn) {
+                            ++ri;
+                            const u32 rj = ri < nrec ? ri : nrec - 1;
+                            a = reg[2 * rj];
+                            b = reg[2 * rj + 1];
+                            cn = rec2_n(b.w);
+                            ctag = rec2_tag(b.w);
+                            o = 0;
+                        }
+                        // the 2k bits of the k-mer that starts at base o: words q .. q + 4 of the record, funnel-shifted
+                        const u32 sh = 2 * o, wq = sh >> 5, r5 = sh & 31u;
+                        const u32 R0 = a.x, R1 = a.y, R2 = a.z, R3 = a.w, R4 = b.x, R5 = b.y, R6 = b.z, R7 = b.w & 0x7ffu;
+                        const bool q1 = wq & 1u, q2 = wq & 2u;
+                        auto sel = [&](u32 v0, u32 v1, u32 v2, u32 v3) -> u32 {
+                            const u32 lo2 = q1 ? v1 : v0, hi2 = q1 ? v3 : v2;
+                            return q2 ? hi2 : lo2;
+                        };
+                        const u32 s0 = sel(R0, R1, R2, R3), s1 = sel(R1, R2, R3, R4), s2 = sel(R2, R3, R4, R5),
+                                  s3 = sel(R3, R4, R5, R6), s4 = sel(R4, R5, R6, R7);
+                        u32 x[4];
+                        x[0] = __builtin_amdgcn_alignbit(s1, s0, r5) & km[0];
+                        x[1] = __builtin_amdgcn_alignbit(s2, s1, r5) & km[1];
+                        x[2] = __builtin_amdgcn_alignbit(s3, s2, r5) & km[2];
+                        x[3] = __builtin_amdgcn_alignbit(s4, s3, r5) & km[3];
+                        // forward key: the window with the order of its bases reversed, right-aligned
+                        const u32 y0 = revpairs32(x[3]), y1 = revpairs32(x[2]), y2 = revpairs32(x[1]), y3 = revpairs32(x[0]);
+                        const u64 ylo = ((u64)y1 << 32) | y0, yhi = ((u64)y3 << 32) | y2;
+                        const u64 flo = (ylo >> fs) | ((yhi << 1) << (63 - fs)), fhi = yhi >> fs;
+                        // reverse complement key: the complemented window
+                        const u64 rlo = ((u64)(x[1] ^ km[1]) << 32) | (x[0] ^ km[0]), rhi = ((u64)(x[3] ^ km[3]) << 32) | (x[2] ^ km[2]);
+                        const bool fwd = fhi < rhi || (fhi == rhi && flo < rlo);
+                        const u64 clo = fwd ? flo : rlo, chi = fwd ? fhi : rhi;
+                        const u32 h = ((u32)clo ^ (u32)(clo >> 32) ^ (u32)chi ^ (u32)(chi >> 32)) * 0x9E3779B1u;
+                        klo[e] = clo;
+                        khi[e] = chi;
+                        slot_[e] = h >> (32 - HBITS);
+                        tagp |= ctag << (8 * e);
+                        if (R == 1 || (((h >> 4) & 0xffffu) * R) >> 16 == q) act |= 1u << e;
+                        ++o;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) { klo[e] = EMPTY; khi[e] = 0; slot_[e] = 0; }
+            }
+            auto tag = [&](int e) -> u32 { return (tagp >> (8 * e)) & 63u; };
+            auto khash = [&](int e) -> u32 {
+                return ((u32)klo[e] ^ (u32)(klo[e] >> 32) ^ (u32)khi[e] ^ (u32)(khi[e] >> 32)) * 0x9E3779B1u;
+            };
+            u32 was[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) was[e] = 0u;
+            // One round: every active key tries its current entry.  Owners publish (high word, ready byte)
+            // before the readers of the same wave look at entries that hold their low word.
+#define SKM2_ROUND(TBL, TMASK)                                                                                         \
+    {                                                                                                                  \
+        unsigned long long old[E];                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                  \
+            old[e] = (act & (1u << e)) ? atomicCAS(&(TBL).klo[slot_[e]], EMPTY, (unsigned long long)klo[e]) : 0ull;    \
+        _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                  \
+            if ((act & (1u << e)) && old[e] == EMPTY) {                                                                \
+                (TBL).khi[slot_[e]] = khi[e];                                                                          \
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                 \
+                (TBL).rdy[slot_[e]] = 1;                                                                               \
+            }                                                                                                          \
+        _Pragma("unroll") for (int e = 0; e < E; ++e) {                                                                \
+            if (act & (1u << e)) {                                                                                     \
+                bool hit = old[e] == EMPTY;                                                                            \
+                if (!hit && old[e] == klo[e]) {                                                                        \
+                    while (!__hip_atomic_load(&(TBL).rdy[slot_[e]], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) {} \
+                    hit = (TBL).khi[slot_[e]] == khi[e];                                                               \
+                }                                                                                                      \
+                if (hit) {                                                                                             \
+                    was[e] = atomicOr(((tag(e) & 32u) ? (TBL).mhi : (TBL).mlo) + slot_[e], 1u << (tag(e) & 31u));      \
+                    act &= ~(1u << e);                                                                                 \
+                } else {                                                                                               \
+                    slot_[e] = (slot_[e] + 1u) & (TMASK);                                                              \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+            for (u32 round = 0; round < (u32)KH_HASH_ROUNDS && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(tbl, T - 1u)
+            if (__builtin_amdgcn_ballot_w64(act != 0)) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const u32 h = khash(e); slot_[e] = ((h ^ (h >> 15)) * 0x85EBCA77u) >> 25; }   // T2 = 128
+                for (u32 round = 0; round < T2 && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(ovf, T2 - 1u)
+                if (__builtin_amdgcn_ballot_w64(act != 0)) {   // second table full of other keys: on in the main table
+#pragma unroll
+                    for (int e = 0; e < E; ++e) slot_[e] = ((khash(e) >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
+                    for (u32 round = 0; round < T && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(tbl, T - 1u)
+                    if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                }
+            }
+#undef SKM2_ROUND
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((was[e] >> (tag(e) & 31u)) & 1u) atomicAdd(&dupc[tag(e)], 1u);
+        }
+        __syncthreads();
+        // ---- every occupied entry is one distinct key of the slot: genome mask -> histogram bins
+        u32 ones = 0;   // keys that sit in exactly one group
+        for (u32 i = tid; i < T + T2; i += NT) {
+            const bool main_t = i < T;
+            const u32 j = main_t ? i : i - T;
+            const unsigned long long kl = main_t ? tbl.klo[j] : ovf.klo[j];
+            if (kl != EMPTY) {
+                const u64 emask = main_t ? (((u64)tbl.mhi[j] << 32) | tbl.mlo[j]) : (((u64)ovf.mhi[j] << 32) | ovf.mlo[j]);
+                const u32 ng = eval_mask(emask, ginfo[__ffsll((unsigned long long)emask) - 1]);
+                if (ng == 1u) ++ones;
+                else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
+            }
+        }
+        ones = wave_scan_add(ones);
+        if (lane == KH_WAVE - 1 && ones) atomicAdd(&hstripe[(jb.abase + 1u) * 8u], ones);
+        __syncthreads();
+    }
+    unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
+    for (u32 i = tid; i < nbins; i += NT) {
+        u32 v = 0;
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) v += hstripe[i * 8u + j];
+        if (v) atomicAdd(&rep[i], (unsigned long long)v);
+    }
+    if (tid < (u32)KH_TAG_MAX_OPS && dupc[tid]) atomicAdd(&jb.dup[tid], (unsigned long long)dupc[tid]);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+template <class K> static void skm2_allow_lds(K kern, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+template <int WW> static void launch_scatter2_w(const KhSkmJob& job, u32 ntiles, size_t lds, hipStream_t st) {
+    skm2_allow_lds(k_skm2_scatter<WW>, lds);
+    hipLaunchKernelGGL(k_skm2_scatter<WW>, dim3(ntiles), dim3(SKM_NT), lds, st, job);
+}
+// m-mers per k-mer the two-word scatter is instantiated for: every third value, so that one of the minimizer
+// lengths 14, 15, 16 fits any k
+bool kh_skm2_supports_w(u32 w) { return w >= 18 && w <= 51 && w % 3 == 0; }
+void kh_launch_skm2_scatter(const KhSkmJob& job, u32 ntiles, hipStream_t st) {
+    if (!ntiles) return;
+    const size_t lds = kh_skm2_scatter_lds_bytes(job.nb1);
+    switch (job.w) {
+#define SKM_W(WW) case WW: launch_scatter2_w<WW>(job, ntiles, lds, st); break;
+        SKM_W(18) SKM_W(21) SKM_W(24) SKM_W(27) SKM_W(30) SKM_W(33) SKM_W(36) SKM_W(39) SKM_W(42) SKM_W(45) SKM_W(48) SKM_W(51)
+#undef SKM_W
+        default: break;   // the host asks kh_skm2_supports_w first
+    }
+}
+void kh_launch_skm2_regroup(const KhSkmJob& job, hipStream_t st) {
+    const size_t lds = kh_skm2_regroup_lds_bytes(job.S);
+    skm2_allow_lds(k_skm2_regroup, lds);
+    hipLaunchKernelGGL(k_skm2_regroup, dim3(job.nb1), dim3(SKM_RG_NT), lds, st, job);
+}
+void kh_launch_skm2_union(const KhSkmJob& job, u32 cs, hipStream_t st) {
+    const size_t lds = kh_skm2_union_lds_bytes(job.nbins);
+    skm2_allow_lds(k_skm2_union, lds);
+    hipLaunchKernelGGL(k_skm2_union, dim3(job.nslots), dim3(SKM2_UNT), lds, st, job, cs);
+}

@@ -1,6 +1,6 @@
-"""The super-k-mer form of the fused path (khoice_amd/csrc/kh_skm.hip: minimizer records -> two
-counting-sort levels -> one LDS hash set per slot; taken by kh_exp1_run for 20 <= k <= 32 when no
-set is requested) against the C restatement of exp_type_1.smk:156-259 and against the library's
+"""The super-k-mer form of the fused path (khoice_amd/csrc/kh_skm.hip, kh_skm2.hip: minimizer records ->
+two counting-sort levels -> one LDS hash set per slot; taken by kh_exp1_run for 20 <= k <= 63 when no
+set is requested; two-word keys from k = 33) against the C restatement of exp_type_1.smk:156-259 and against the library's
 key-array form on the same inputs.  Bit-exact: histograms and per-genome distinct counts."""
 import os
 import random
@@ -60,6 +60,75 @@ def test_skm_matches_oracle_over_k(eng, k):
     seqs = [t for _, _, t in items]
     group_of = [s - 1 for s, _, _ in items]
     check(eng, seqs, group_of, k)
+
+
+@pytest.mark.parametrize("k", [33, 34, 36, 40, 41, 47, 48, 49, 55, 62, 63])
+def test_skm_two_word_keys_match_oracle_over_k(eng, k):
+    """32-byte records, windows of 18 .. 51 m-mers (hashes of the next TWO threads), the two-step claim of the
+    128-bit hash set."""
+    items = synth.species_set(3, 3, 60_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    check(eng, seqs, group_of, k)
+
+
+def test_skm_two_word_keys_edges_and_shapes(eng):
+    rng = random.Random(17)
+    anc = random_dna(rng, 30_000)
+    body = random_dna(rng, 40_000)
+    seqs = [
+        anc.encode(),
+        (anc[:15_000].lower() + "N" * 40 + anc[15_000:]).encode(),
+        b"ACGT", b"",
+        ("A" * 20_000 + "\n" + anc[:5_000]).encode(),                   # one minimizer for 20 000 positions: long runs cut at nmax
+        ("AC" * 10_000).encode(),
+        ("T" * 5_000 + "A" * 5_000).encode(),                           # ends in / starts with 32 T: the low key word near all-ones
+    ]
+    for cut in (8191, 8192, 8192 + 30, 16384 - 63, 16384 + 1):
+        seqs.append((body[:cut] + "N" + body[cut:cut + 5_000] + "\n" + body[cut + 5_000:cut + 5_777]).encode())
+    seqs.append(body[:8192 + 62].encode())
+    seqs.append(body[:63].encode())
+    group_of = [i % 4 for i in range(len(seqs))]
+    for k in (33, 41, 63):
+        check(eng, seqs, group_of, k, cs=5000, hist_len=64, expect_skm=False)
+    # 64 operands, repeats inside genomes
+    sizes = [1, 2, 30, 7, 24]
+    seqs, group_of = [], []
+    for g, sz in enumerate(sizes):
+        a = random_dna(rng, 20_000)
+        for j in range(sz):
+            t = list(a)
+            for _ in range(len(t) // 200):
+                t[rng.randrange(len(t))] = rng.choice("ACGT")
+            s2 = "".join(t)
+            if j % 4 == 1:
+                s2 += "\n" + s2[1000:3000]
+            seqs.append(s2.encode())
+            group_of.append(g)
+    check(eng, seqs, group_of, 41)
+    check(eng, seqs, group_of, 63, cs=3, hist_len=8)
+
+
+def test_skm_two_word_keys_overfull_slots_and_form_equivalence(eng):
+    items = synth.species_set(3, 4, 100_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    got, _ = run_skm(eng, seqs, group_of, 41)
+    os.environ["KHOICE_NO_SKM"] = "1"
+    try:
+        ref, ran = run_skm(eng, seqs, group_of, 41, expect_skm=False)
+    finally:
+        del os.environ["KHOICE_NO_SKM"]
+    assert ran == 0
+    same(got, ref)
+    os.environ["KHOICE_SKM_MEAN"] = "3000"      # > 2048 table entries: two key subsets per slot
+    os.environ["KHOICE_SKM_SLACK"] = "1.1"
+    try:
+        check(eng, seqs, group_of, 41)
+        check(eng, seqs, group_of, 63)
+    finally:
+        del os.environ["KHOICE_SKM_MEAN"]
+        del os.environ["KHOICE_SKM_SLACK"]
 
 
 def test_skm_matches_key_array_form(eng):
