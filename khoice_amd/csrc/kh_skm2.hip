@@ -7,9 +7,10 @@
 //   * a k-mer has up to 49 m-mers: the sliding minimum needs the hashes of the NEXT TWO threads (two DPP
 //     wave_shl steps) and 96 validity flags per thread;
 //   * the hash set cannot claim a 128-bit key with one compare-and-swap.  An entry is claimed on the LOW word
-//     (compare-and-swap against the empty marker); the winner then stores the high word and sets the entry's
-//     ready byte (LDS operations of one wave are performed in order).  A key that finds its own low word in an
-//     entry waits for the ready byte and compares the high word: equal — its entry; different — another key
+//     (compare-and-swap against the empty marker); the winner then stores the high word over the "not yet"
+//     marker the entry was cleared with (a high word has at most 62 bits for k <= 63; one aligned 8-byte LDS
+//     store).  A key that finds its own low word in an entry reads the high word until it is no longer the
+//     marker and compares: equal — its entry; different — another key
 //     (same low word: as good as never), on to the next entry.  In every round the owners publish before the
 //     readers of the same wave look, so a wave never waits for itself; other waves run on without barriers.
 //     The all-ones low word cannot be canonical for k <= 63 (a k-mer that ends in 32 T has a reverse
@@ -310,7 +311,7 @@ constexpr u32 SKM2_URPT = 1024 / SKM2_UNT;         // records per thread when th
 constexpr u32 SKM2_SPEC = 320;                     // records of a slot read before their number is known
 constexpr u32 SKM2_OWN = 2048;                     // chunk owners: a slot of up to SKM2_UE * 2048 k-mer instances
 size_t kh_skm2_union_lds_bytes(u32 nbins) {
-    return (size_t)SKM2_UT * 25 + (size_t)SKM2_UT2 * 25 + 128 + 256 + 128 + 256 + (((size_t)nbins * 32 + 15) & ~(size_t)15) +
+    return (size_t)SKM2_UT * 24 + (size_t)SKM2_UT2 * 24 + 256 + 128 + 256 + (((size_t)nbins * 32 + 15) & ~(size_t)15) +
            (size_t)(SKM2_URPT * SKM2_UNT + 8) * 2 + (size_t)SKM2_OWN * 2;
 }
 u32 kh_skm2_max_cap2() { return SKM2_URPT * SKM2_UNT; }
@@ -321,19 +322,17 @@ __global__ __launch_bounds__(SKM2_UNT, 2 * (SKM2_UNT / 64) / 4) void k_skm2_unio
     constexpr u32 NT = SKM2_UNT, T = SKM2_UT, T2 = SKM2_UT2, HBITS = 11;
     constexpr int E = (int)SKM2_UE;
     constexpr u64 EMPTY = ~0ull;   // never the low word of a canonical key for k <= 63 (see the head of the file)
-    struct Tbl { unsigned long long* klo; unsigned long long* khi; u32* mlo; u32* mhi; u8* rdy; };
+    struct Tbl { unsigned long long* klo; unsigned long long* khi; u32* mlo; u32* mhi; };
     u8* p = lds_raw;
     Tbl tbl, ovf;
     tbl.klo = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T * 8;
     tbl.khi = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T * 8;
     tbl.mlo = reinterpret_cast<u32*>(p);                      p += (size_t)T * 4;
     tbl.mhi = reinterpret_cast<u32*>(p);                      p += (size_t)T * 4;
-    tbl.rdy = p;                                              p += (size_t)T;
     ovf.klo = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T2 * 8;
     ovf.khi = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T2 * 8;
     ovf.mlo = reinterpret_cast<u32*>(p);                      p += (size_t)T2 * 4;
     ovf.mhi = reinterpret_cast<u32*>(p);                      p += (size_t)T2 * 4;
-    ovf.rdy = p;                                              p += (size_t)T2 + 128;
     u32* ginfo = reinterpret_cast<u32*>(p);                   p += 256;
     u32* scratch = reinterpret_cast<u32*>(p);                 p += 128;
     u32* dupc = reinterpret_cast<u32*>(p);                    p += 256;
@@ -353,9 +352,12 @@ __global__ __launch_bounds__(SKM2_UNT, 2 * (SKM2_UNT / 64) / 4) void k_skm2_unio
         const u32 i = SKM2_URPT * tid + j;
         top[j] = i < (cap2 < SKM2_SPEC ? cap2 : SKM2_SPEC) ? reg[2 * i + 1].w : 0u;
     }
-    auto clear_tables = [&]() {
-        for (u32 i = tid; i < T; i += NT) { tbl.klo[i] = EMPTY; tbl.mlo[i] = 0u; tbl.mhi[i] = 0u; tbl.rdy[i] = 0; }
-        for (u32 i = tid; i < T2; i += NT) { ovf.klo[i] = EMPTY; ovf.mlo[i] = 0u; ovf.mhi[i] = 0u; ovf.rdy[i] = 0; }
+    auto clear_tables = [&]() {   // key words all ones (low: empty, high: not yet published), masks zero
+        uint4* k4 = reinterpret_cast<uint4*>(tbl.klo);    // T * 16 bytes of ones (both key planes), then T * 8 bytes of zeros
+        uint4* m4 = reinterpret_cast<uint4*>(tbl.mlo);
+        for (u32 i = tid; i < T; i += NT) k4[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        for (u32 i = tid; i < T / 2; i += NT) m4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (u32 i = tid; i < T2; i += NT) { ovf.klo[i] = EMPTY; ovf.khi[i] = EMPTY; ovf.mlo[i] = 0u; ovf.mhi[i] = 0u; }
     };
     for (u32 i = tid; i < (u32)KH_TAG_MAX_OPS; i += NT) { ginfo[i] = jb.ginfo[i]; dupc[i] = 0; }
     for (u32 i = tid; i < nbins * 8u; i += NT) hstripe[i] = 0;
@@ -490,25 +492,24 @@ __global__ __launch_bounds__(SKM2_UNT, 2 * (SKM2_UNT / 64) / 4) void k_skm2_unio
             u32 was[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) was[e] = 0u;
-            // One round: every active key tries its current entry.  Owners publish (high word, ready byte)
-            // before the readers of the same wave look at entries that hold their low word.
+            // One round: every active key tries its current entry.  Owners publish their high word before the
+            // readers of the same wave look at entries that hold their low word.
 #define SKM2_ROUND(TBL, TMASK)                                                                                         \
     {                                                                                                                  \
         unsigned long long old[E];                                                                                     \
         _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                  \
             old[e] = (act & (1u << e)) ? atomicCAS(&(TBL).klo[slot_[e]], EMPTY, (unsigned long long)klo[e]) : 0ull;    \
         _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                  \
-            if ((act & (1u << e)) && old[e] == EMPTY) {                                                                \
-                (TBL).khi[slot_[e]] = khi[e];                                                                          \
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                 \
-                (TBL).rdy[slot_[e]] = 1;                                                                               \
-            }                                                                                                          \
+            if ((act & (1u << e)) && old[e] == EMPTY)                                                                  \
+                __hip_atomic_store(&(TBL).khi[slot_[e]], (unsigned long long)khi[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
         _Pragma("unroll") for (int e = 0; e < E; ++e) {                                                                \
             if (act & (1u << e)) {                                                                                     \
                 bool hit = old[e] == EMPTY;                                                                            \
                 if (!hit && old[e] == klo[e]) {                                                                        \
-                    while (!__hip_atomic_load(&(TBL).rdy[slot_[e]], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) {} \
-                    hit = (TBL).khi[slot_[e]] == khi[e];                                                               \
+                    unsigned long long h2;                                                                             \
+                    do h2 = __hip_atomic_load(&(TBL).khi[slot_[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+                    while (h2 == EMPTY);                                                                               \
+                    hit = h2 == khi[e];                                                                                \
                 }                                                                                                      \
                 if (hit) {                                                                                             \
                     was[e] = atomicOr(((tag(e) & 32u) ? (TBL).mhi : (TBL).mlo) + slot_[e], 1u << (tag(e) & 31u));      \
