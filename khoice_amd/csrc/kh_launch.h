@@ -121,7 +121,10 @@ struct KhTagJob {
 // minimizer slot, partitioned in two levels (coarse bucket, then slot = coarse * S + fine), then one LDS
 // hash set per slot.  A record is 16 bytes: bits [0, 2(n+k-1)) the bases (base j at bits 2j, A0 C1 G2 T3),
 // bits 108..116 the fine index of its slot, 117..122 the genome (operand) number, 123..127 n.
-constexpr u32 KH_SKM_STAGE = 1536;        // records counting-sorted in LDS per flush of the scatter
+#ifndef KH_TUNE_SKM_STAGE
+#define KH_TUNE_SKM_STAGE 2048   // (1024 / 1536 / 2048 / 2304 / 2560: scatter 0.82 / 0.68 / 0.645 / 0.69 / 0.735 ms; above 2048 only two workgroups fit a CU)
+#endif
+constexpr u32 KH_SKM_STAGE = KH_TUNE_SKM_STAGE;   // records counting-sorted in LDS per flush of the scatter
 constexpr u32 KH_SKM_MAX_COARSE = 256;    // coarse buckets (LDS counters of the scatter)
 constexpr u32 KH_SKM_MAX_FINE = 512;      // slots per coarse bucket (9 bits in the record)
 constexpr u32 KH_SKM_MAX_CAP2 = 2048;     // records of one slot (the union reads four per thread)
