@@ -50,10 +50,13 @@ void kh_debug_set_stamps_skm(u64* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_skm_
 #define KH_TUNE_SKM_FULL_ROUNDS KH_TUNE_HASH_ROUNDS   // probe rounds made by all keys of a thread together; the rest one key per lane
 #endif
 #ifndef KH_TUNE_SKM_PREFETCH
-#define KH_TUNE_SKM_PREFETCH 0   // union: keep the record behind the current one in registers (four more VGPRs: spills at 64)
+#define KH_TUNE_SKM_PREFETCH 1   // union: the record behind the current one waits in registers (1.741 -> 1.725 ms; fits the 64 VGPRs since the addresses of the read-out are formed late)
 #endif
 #ifndef KH_TUNE_SKM_OVF_SERIAL
 #define KH_TUNE_SKM_OVF_SERIAL 1
+#endif
+#ifndef KH_TUNE_SKM_SCATTER_PREFETCH
+#define KH_TUNE_SKM_SCATTER_PREFETCH 0   // 1: the next sub-tile's bases wait in registers while this one is processed (0.656 ms against 0.624: three workgroups per CU hide the load as well, with fewer registers)
 #endif
 #ifndef KH_TUNE_SKM_SCATTER_WAVES
 #define KH_TUNE_SKM_SCATTER_WAVES 3   // waves per SIMD the scatter is compiled for (workgroups of 4 waves per CU)
@@ -98,17 +101,24 @@ __global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatt
     u32 staged = 0, tile_recs = 0;   // uniform
 
     SkmFetch pre;
+#if KH_TUNE_SKM_SCATTER_PREFETCH
     skm_fetch(sg.seq, sg.len, tile_pos0, pre);
+#endif
     for (int sub = 0; sub < subtiles; ++sub) {
         const u64 p0 = tile_pos0 + (u64)sub * SKM_SUB;
         if (p0 >= sg.npos) break;   // uniform
         __syncthreads();
         const bool stamp = sub == 1;
         if (stamp) SKM_STAMP(0);
+#if !KH_TUNE_SKM_SCATTER_PREFETCH
+        skm_fetch(sg.seq, sg.len, p0, pre);
+#endif
         skm_store(pre, code, bad16);
         __syncthreads();
         if (stamp) SKM_STAMP(1);
+#if KH_TUNE_SKM_SCATTER_PREFETCH
         if (sub + 1 < subtiles && p0 + SKM_SUB < sg.npos) skm_fetch(sg.seq, sg.len, p0 + SKM_SUB, pre);
+#endif
         // ---- hashes of the m-mers starting at the thread's 32 positions (32-bit rolling words)
         u32 cw[6];   // bases p .. p + 95: a record starts in the thread's 32 positions and may run on into the next thread's
 #pragma unroll
