@@ -132,7 +132,11 @@ def test_cfg2_full_size_5x5x5mbp(eng):
     items = synth.species_set(5, 5, 5_000_000)
     seqs = [t for _, _, t in items]
     group_of = [s - 1 for s, _, _ in items]
+    eng.profile(True)
+    before = eng.stats()["kernels"]["skm_union"]["launches"]
     got = eng.exp1_run(seqs, group_of, 31, cs=5000, hist_len=5001)
+    assert eng.stats()["kernels"]["skm_union"]["launches"] - before == 1      # the super-k-mer form ran (no fall-back)
+    eng.profile(False)
     want = CO.exp1(seqs, group_of, 31, cs=5000, hist_len=5001)
     assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
     assert (got["within_hist"] == want["within_hist"]).all()
@@ -155,6 +159,27 @@ def test_cfg2_full_size_5x5x5mbp(eng):
             assert O.encode(O.canonical_str(w)) in have
             checked += 1
     assert checked > 10_000
+
+
+@pytest.mark.parametrize("k", [21, 41, 63])
+def test_cfg2_full_size_other_k_super_kmer_form(eng, k):
+    """The same 5 x 5 x 5 Mbp set at a narrow window (k = 21: seven m-mers per k-mer) and with two-word keys
+    (k = 41, 63: 32-byte records, the two-step claim of the 128-bit hash set) against the C restatement."""
+    from khoice_amd import synth
+    from oracle import c_oracle as CO
+    items = synth.species_set(5, 5, 5_000_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    eng.profile(True)
+    before = eng.stats()["kernels"]["skm_union"]["launches"]
+    got = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=5001)
+    assert eng.stats()["kernels"]["skm_union"]["launches"] - before == 1
+    eng.profile(False)
+    want = CO.exp1(seqs, group_of, k, cs=5000, hist_len=5001)
+    assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+    assert (got["within_hist"] == want["within_hist"]).all()
+    assert (got["across_hist"] == want["across_hist"]).all()
+    eng.trim()
 
 
 @pytest.mark.parametrize("k", [31, 41])
