@@ -1585,8 +1585,9 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     }
     if (const char* e = getenv("KHOICE_SKM_MEAN")) mean = std::max<u32>(64, (u32)strtoul(e, nullptr, 10));
     const u64 nslots64 = std::max<u64>(1, (total_pos + mean - 1) / mean);
-    const u32 max_coarse = two ? KH_SKM2_MAX_COARSE : KH_SKM_MAX_COARSE;
-    if (nslots64 > (u64)max_coarse * KH_SKM_MAX_FINE) return KH_OK;
+    // coarse buckets: 256 keep the scatter's runs long; inputs past 256 x 512 slots (> 400 M k-mers) take 512
+    const u32 max_coarse = (two || nslots64 > (u64)KH_SKM_MAX_COARSE * KH_SKM_MAX_FINE) ? KH_SKM2_MAX_COARSE : KH_SKM_MAX_COARSE;
+    if (nslots64 > (u64)max_coarse * (two ? KH_SKM2_MAX_FINE : KH_SKM_MAX_FINE)) return KH_OK;
     const u32 nslots = (u32)nslots64;
     const u32 S = std::max<u32>(1, (nslots + max_coarse - 1) / max_coarse);
     const u32 nb1 = (nslots + S - 1) / S;

@@ -125,7 +125,7 @@ struct KhTagJob {
 #define KH_TUNE_SKM_STAGE 2048   // (1024 / 1536 / 2048 / 2304 / 2560: scatter 0.82 / 0.68 / 0.645 / 0.69 / 0.735 ms; above 2048 only two workgroups fit a CU)
 #endif
 constexpr u32 KH_SKM_STAGE = KH_TUNE_SKM_STAGE;   // records counting-sorted in LDS per flush of the scatter
-constexpr u32 KH_SKM_MAX_COARSE = 256;    // coarse buckets (LDS counters of the scatter)
+constexpr u32 KH_SKM_MAX_COARSE = 256;    // coarse buckets (LDS counters of the scatter); 512 (KH_SKM2_MAX_COARSE) for inputs too large for 256
 constexpr u32 KH_SKM_MAX_FINE = 512;      // slots per coarse bucket (9 bits in the record)
 constexpr u32 KH_SKM_MAX_CAP2 = 2048;     // records of one slot (the union reads four per thread)
 constexpr int KH_SKM_MIN_K = 20, KH_SKM_MAX_K = 32;
@@ -164,6 +164,7 @@ void kh_launch_skm_union(const KhSkmJob& job, u32 cs, hipStream_t st);
 // the same three steps for two-word keys (kh_skm2.hip): 32-byte records (two uint4 per record in reg1 / reg2)
 constexpr int KH_SKM2_MAX_K = 63;         // k = 64: the all-ones low key word is a k-mer (A^32 T^32)
 constexpr u32 KH_SKM2_MAX_COARSE = 512;
+constexpr u32 KH_SKM2_MAX_FINE = 1024;    // slots per coarse bucket with two-word keys (10 bits in the record)
 bool kh_skm2_supports_w(u32 w);
 u32 kh_skm2_max_cap2();
 u32 kh_skm2_table();

@@ -3,7 +3,7 @@
 // Same three steps as kh_skm.hip (which see: minimizer records, two LDS counting-sort levels, one LDS hash
 // set per slot), with what 2k > 64 bits changes:
 //   * a record is 32 bytes: bits [0, 2(n+k-1)) the bases, in the last word n (6 bits, 26..31), the genome
-//     number (20..25), the fine slot index (11..19); n <= min(63, 118 - k);
+//     number (20..25), the fine slot index (10 bits, 10..19); n <= min(63, 118 - k);
 //   * a k-mer has up to 49 m-mers: the sliding minimum needs the hashes of the NEXT TWO threads (two DPP
 //     wave_shl steps) and 96 validity flags per thread;
 //   * the hash set cannot claim a 128-bit key with one compare-and-swap.  An entry is claimed on the LOW word
@@ -34,7 +34,7 @@ constexpr u32 SKM2_CWN = 10;                    // code words a thread keeps: ba
 
 __device__ __forceinline__ u32 rec2_n(u32 w7) { return w7 >> 26; }
 __device__ __forceinline__ u32 rec2_tag(u32 w7) { return (w7 >> 20) & 63u; }
-__device__ __forceinline__ u32 rec2_fine(u32 w7) { return (w7 >> 11) & 511u; }
+__device__ __forceinline__ u32 rec2_fine(u32 w7) { return (w7 >> 10) & 1023u; }
 
 }   // namespace
 
@@ -211,13 +211,13 @@ __global__ __launch_bounds__(SKM_NT, 2) void k_skm2_scatter(const KhSkmJob jb) {
                         u32 src[9], out[8];
 #pragma unroll
                         for (int i = 0; i < 9; ++i) src[i] = up ? cw[i + 1] : cw[i];
-                        const u32 bits = 2 * (n + (u32)k - 1);   // <= 236
+                        const u32 bits = 2 * (n + (u32)k - 1);   // <= 234: the bases end below the header (bit 10 of the last word)
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const u32 wv = __builtin_amdgcn_alignbit(src[i + 1], src[i], r5);
                             out[i] = bits >= 32u * (i + 1) ? wv : (bits > 32u * i ? wv & ((1u << (bits - 32u * i)) - 1u) : 0u);
                         }
-                        out[7] |= (fine << 11) | (t.seg << 20) | (n << 26);
+                        out[7] |= (fine << 10) | (t.seg << 20) | (n << 26);
                         L.stage[2 * at] = make_uint4(out[0], out[1], out[2], out[3]);
                         L.stage[2 * at + 1] = make_uint4(out[4], out[5], out[6], out[7]);
                         L.sid[at] = (u16)coarse;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(SKM2_UNT, 2 * (SKM2_UNT / 64) / 4) void k_skm2_unio
                         }
                         // the 2k bits of the k-mer that starts at base o: words q .. q + 4 of the record, funnel-shifted
                         const u32 sh = 2 * o, wq = sh >> 5, r5 = sh & 31u;
-                        const u32 R0 = a.x, R1 = a.y, R2 = a.z, R3 = a.w, R4 = b.x, R5 = b.y, R6 = b.z, R7 = b.w & 0x7ffu;
+                        const u32 R0 = a.x, R1 = a.y, R2 = a.z, R3 = a.w, R4 = b.x, R5 = b.y, R6 = b.z, R7 = b.w & 0x3ffu;
                         const bool q1 = wq & 1u, q2 = wq & 2u;
                         auto sel = [&](u32 v0, u32 v1, u32 v2, u32 v3) -> u32 {
                             const u32 lo2 = q1 ? v1 : v0, hi2 = q1 ? v3 : v2;
