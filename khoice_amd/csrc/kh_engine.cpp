@@ -2072,7 +2072,12 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
                 bool done = false;
                 u64 bbases = 0;
                 for (int g = g0; g < g1; ++g) bbases += gbases[g];
-                int r = exp1_fused(c, (int)idx.size(), bs.data(), bl.data(), on_device, bg.data(), g1 - g0, k, cs,
+                int r = KH_OK;
+                if (!want_across)   // steps 1-4 only (more than 64 genomes, no across-group step): the batches are independent
+                    r = exp1_skm(c, (int)idx.size(), bs.data(), bl.data(), on_device, bg.data(), g1 - g0, k, cs,
+                                 within_hist ? within_hist + (size_t)g0 * hist_len : nullptr, nullptr, hist_len, bd.data(), &done);
+                if (r == KH_OK && !done)
+                    r = exp1_fused(c, (int)idx.size(), bs.data(), bl.data(), on_device, bg.data(), g1 - g0, k, cs,
                                    within_hist ? within_hist + (size_t)g0 * hist_len : nullptr, nullptr, hist_len,
                                    bd.data(), want_across ? &aset : nullptr, &done, waves_for(bbases));
                 if (r != KH_OK) { drop(); return r; }

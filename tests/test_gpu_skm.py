@@ -213,6 +213,26 @@ def test_skm_many_genomes_and_groups(eng):
     check(eng, seqs, group_of, 21, cs=3, hist_len=8)
 
 
+def test_skm_more_than_64_genomes_without_across_step(eng):
+    """Steps 1-4 only (BASELINE configs[2]: 10 x 10 genomes, within-group occurrence): batches of whole groups of
+    at most 64 genomes are independent, each takes the super-k-mer form."""
+    items = synth.species_set(7, 10, 30_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    for k in (31, 41):
+        want = CO.exp1(seqs, group_of, k, cs=5000, hist_len=64)
+        eng.profile(True)
+        before = skm_launches(eng)
+        got = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64, across=False)
+        ran = skm_launches(eng) - before
+        eng.profile(False)
+        assert ran == 2                                   # 6 groups (60 genomes) + 1 group
+        assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+        assert (got["within_hist"] == want["within_hist"]).all()
+        full = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64)      # with the across-group step: key arrays
+        assert (full["within_hist"] == want["within_hist"]).all() and (full["across_hist"] == want["across_hist"]).all()
+
+
 def test_skm_overfull_slot_rounds(eng):
     """Slots far above the hash set's capacity (KHOICE_SKM_MEAN forces few, large slots): key subsets
     are handled in rounds, several index passes per round."""
