@@ -1522,14 +1522,17 @@ static int group_union_incremental(kh_ctx* c, const std::vector<int>& members, c
 // slot.  Takes what the key-array form below takes when k is in [KH_SKM_MIN_K, KH_SKM_MAX_K], nothing is
 // emitted and the batch fits one slot grid; *done == false: not applicable, or a region overflowed
 // (low-complexity input, far more records than estimated) — the caller goes on to the key-array form.
+// by_group: the operands of the union are the GROUPS (every record carries its genome's group number): only the
+// across-group histogram comes out — the second pass of a run over more than 64 genomes, whose batches of
+// whole groups have answered the within-group questions.
 static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                     const int* group_of, int ngroups, int k, u32 cs, uint64_t* within_hist,
-                    uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, bool* done) {
+                    uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, bool* done, bool by_group = false) {
     *done = false;
     if (k < KH_SKM_MIN_K || k > KH_SKM2_MAX_K || getenv("KHOICE_NO_SKM")) return KH_OK;
     const bool two = k > KH_SKM_MAX_K;   // two-word keys: 32-byte records, kh_skm2.hip
     if (two && getenv("KHOICE_NO_SKM2")) return KH_OK;
-    if (nseq > KH_TAG_MAX_OPS || ngroups > KH_TAG_MAX_OPS) return KH_OK;
+    if ((!by_group && nseq > KH_TAG_MAX_OPS) || ngroups > KH_TAG_MAX_OPS) return KH_OK;
     std::vector<int> gsize(ngroups, 0), gstart(ngroups + 1, 0), perm(nseq);
     for (int i = 0; i < nseq; ++i) gsize[group_of[i]]++;
     u32 nbins = 0;
@@ -1538,7 +1541,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         if (!gsize[g]) return kh_fail(KH_E_ARG, "group %d has no sequences", g);
         gstart[g + 1] = gstart[g] + gsize[g];
         bin0[g] = nbins;
-        nbins += (u32)gsize[g] + 1;
+        nbins += (by_group ? 1u : (u32)gsize[g]) + 1;   // by_group: every operand is a group of its own
     }
     const u32 abase = nbins;
     nbins += (u32)ngroups + 1;
@@ -1576,12 +1579,14 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     // (largest group) instances, so sigma = sqrt(mean x c); mean + 2.5 sigma = T  (measured: 2500 / 2900 / 3200 /
     // 3500 / 3800 at k = 31 with groups of five: union 1.96 / 1.81 / 1.75 / 1.80 / 1.94 ms; the rule gives 3180)
     u32 mean;
+    double clump = 1.0;   // instances that land in a slot together
     {
         u32 fan = 1;
         for (int g = 0; g < ngroups; ++g) fan = std::max<u32>(fan, (u32)gsize[g]);
         const double T = two ? (double)kh_skm2_table() : 4096.0, cl = 0.5 * (double)(w + 1) * (double)fan;
         const double r = 0.5 * (-2.5 * std::sqrt(cl) + std::sqrt(6.25 * cl + 4.0 * T));
         mean = (u32)std::max(256.0, r * r);
+        clump = cl;
     }
     if (const char* e = getenv("KHOICE_SKM_MEAN")) mean = std::max<u32>(64, (u32)strtoul(e, nullptr, 10));
     const u64 nslots64 = std::max<u64>(1, (total_pos + mean - 1) / mean);
@@ -1596,7 +1601,9 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     // a little (measured: 0.120 records per k-mer at w = 16, 0.27 at w = 7)
     const double per_kmer = 2.0 / (double)(w + 1) + 1.0 / 48.0;
     const double recs = (double)total_pos * per_kmer;
-    double slack1 = 1.25, slack2 = 1.7;
+    // a slot's records vary like its instances: sigma / mean = sqrt(clump / mean) (12 % at k = 31 with groups of five,
+    // 36 % with ten genomes per group and two-word keys): five sigma, at least 1.7
+    double slack1 = 1.25, slack2 = std::max(1.7, 1.0 + 5.0 * std::sqrt(clump / (double)mean));
     if (const char* e = getenv("KHOICE_SKM_SLACK")) slack1 = slack2 = std::max(0.01, atof(e));   // below 1: tests of the overflow fall-back
     const u64 cap1_64 = ((u64)(recs / nb1 * slack1) + 2048 + 63) & ~63ull;
     const u64 cap2_64 = ((u64)(recs / nslots * slack2) + 96 + 15) & ~15ull;
@@ -1641,7 +1648,8 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     // workspace: [hist][ctl: 8 u32][inst: nseq u64][dup: 64 u64][cur1: nb1 u32][cur2: nslots u32] (zeroed) [ginfo: 64 u32]
     const size_t off_ctl = 8 * hist_words, off_inst = off_ctl + 32, off_dup = off_inst + 8 * (size_t)nseq,
                  off_cur1 = off_dup + 8 * 64, off_cur2 = off_cur1 + 4 * (size_t)KH_SKM_CUR1_STRIDE * nb1,
-                 off_ginfo = off_cur2 + 4 * (size_t)((nslots + 3) & ~3u), ws_bytes = off_ginfo + 256;
+                 off_ginfo = off_cur2 + 4 * (size_t)((nslots + 3) & ~3u), off_tags = off_ginfo + 256,
+                 ws_bytes = off_tags + (((size_t)nseq + 15) & ~(size_t)15);
     Tmp d_seq, d_segs, d_tiles, d_ws, d_reg1, d_reg2;
     bool need_pack = false;
     for (int i = 0; i < nseq; ++i)
@@ -1654,7 +1662,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     TMP_ALLOC(d_reg2, c, reg2_bytes);
     struct PinG { kh_ctx* c; void* p = nullptr; size_t n = 0; ~PinG() { if (p) c->pin_release(p, n); } } pin{c};
     // pinned staging: [segs][tiles][ginfo] up, [hist .. dup] down
-    const size_t up_bytes = sizeof(KhSeg) * nseq + sizeof(KhTile) * (size_t)ntiles + 256;
+    const size_t up_bytes = sizeof(KhSeg) * nseq + sizeof(KhTile) * (size_t)ntiles + 256 + (((size_t)nseq + 15) & ~(size_t)15);
     const size_t down_bytes = off_cur1;
     pin.p = c->pin_alloc(up_bytes + down_bytes + 64, &pin.n);
     if (!pin.p) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
@@ -1674,18 +1682,25 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     u32* h_ginfo = reinterpret_cast<u32*>(h_up + sizeof(KhSeg) * nseq + sizeof(KhTile) * (size_t)ntiles);
     memcpy(h_segs, segs.data(), sizeof(KhSeg) * nseq);
     if (ntiles) memcpy(h_tiles, tiles.data(), sizeof(KhTile) * (size_t)ntiles);
+    u8* h_tags = reinterpret_cast<u8*>(h_ginfo + 64);
     memset(h_ginfo, 0, 256);
-    for (int g = 0; g < ngroups; ++g)
-        for (int j = 0; j < gsize[g]; ++j)
-            h_ginfo[gstart[g] + j] = (u32)gstart[g] | ((u32)gsize[g] << 8) | (bin0[g] << 16);
+    if (by_group) {
+        for (int g = 0; g < ngroups; ++g) h_ginfo[g] = (u32)g | (1u << 8) | (bin0[g] << 16);
+        for (int i = 0; i < nseq; ++i) h_tags[i] = (u8)group_of[perm[i]];
+    } else {
+        for (int g = 0; g < ngroups; ++g)
+            for (int j = 0; j < gsize[g]; ++j)
+                h_ginfo[gstart[g] + j] = (u32)gstart[g] | ((u32)gsize[g] << 8) | (bin0[g] << 16);
+    }
     HIPCHK(hipMemcpyAsync(d_segs.b->p, h_segs, sizeof(KhSeg) * nseq, hipMemcpyHostToDevice, st));
     if (ntiles) HIPCHK(hipMemcpyAsync(d_tiles.b->p, h_tiles, sizeof(KhTile) * (size_t)ntiles, hipMemcpyHostToDevice, st));
     u8* wsp = d_ws.as<u8>();
     HIPCHK(hipMemsetAsync(wsp, 0, off_ginfo, st));
-    HIPCHK(hipMemcpyAsync(wsp + off_ginfo, h_ginfo, 256, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(wsp + off_ginfo, h_ginfo, 256 + (by_group ? (size_t)nseq : 0), hipMemcpyHostToDevice, st));
     c->prof_end();
 
     KhSkmJob job;
+    job.seg_tag = by_group ? wsp + off_tags : nullptr;
     job.segs = d_segs.as<KhSeg>();
     job.tiles = d_tiles.as<KhTile>();
     job.reg1 = d_reg1.as<uint4>();
@@ -1700,7 +1715,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     job.tile_pos = tile_pos;
     job.k = k; job.m = m; job.w = w; job.nmax = nmax;
     job.nslots = nslots; job.S = S; job.nb1 = nb1; job.cap1 = cap1; job.cap2 = cap2;
-    job.nbins = nbins; job.abase = abase; job.reps = reps; job.nops = (u32)nseq;
+    job.nbins = nbins; job.abase = abase; job.reps = reps; job.nops = by_group ? (u32)ngroups : (u32)nseq;
 #ifdef KH_STAMPS
     Tmp d_stamps;
     const u64 nst = std::max<u64>(ntiles, nslots);
@@ -1757,24 +1772,26 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         c->stat.retries++;
         return KH_OK;   // a region or a slot overflowed: the key-array form takes over
     }
-    c->stat.bases += bases;
-    c->stat.builds += nseq;
     c->stat.skm_records += h_ctl[2];
-    u64 inst = 0, dsum = 0;
-    for (int i = 0; i < nseq; ++i) {
-        const u64 d = h_inst[i] - h_dup[i];
-        inst += h_inst[i];
-        dsum += d;
-        if (distinct_per_seq) distinct_per_seq[perm[i]] = d;
+    if (!by_group) {
+        c->stat.bases += bases;
+        c->stat.builds += nseq;
+        u64 inst = 0, dsum = 0;
+        for (int i = 0; i < nseq; ++i) {
+            const u64 d = h_inst[i] - h_dup[i];
+            inst += h_inst[i];
+            dsum += d;
+            if (distinct_per_seq) distinct_per_seq[perm[i]] = d;
+        }
+        c->stat.kmers += inst;
+        c->stat.distinct += dsum;
+        c->stat.setop_in += dsum;
     }
-    c->stat.kmers += inst;
-    c->stat.distinct += dsum;
     c->stat.setops++;
-    c->stat.setop_in += dsum;
     std::vector<u64> bins(nbins, 0);
     for (u32 r = 0; r < reps; ++r)
         for (u32 b = 0; b < nbins; ++b) bins[b] += h_hist[(size_t)r * nbins + b];
-    if (within_hist) {
+    if (within_hist && !by_group) {
         memset(within_hist, 0, 8 * (size_t)ngroups * hist_len);
         for (int g = 0; g < ngroups; ++g)
             for (int cnt = 1; cnt <= gsize[g]; ++cnt)
@@ -2055,6 +2072,42 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
             }
         } else if (applicable) {
             const bool want_across = across_hist || across_set;
+            // Histograms only, more than 64 genomes: every batch in the super-k-mer form for the within-group
+            // questions, then ONE more pass over all genomes whose records carry the group number for the
+            // across-group one.  Anything it cannot take (a region overflow, k outside its range) -> the key arrays.
+            if (!across_set && across_hist && ngroups <= KH_TAG_MAX_OPS && !getenv("KHOICE_NO_SKM_TWO_PASS")) {
+                bool ok2 = true;
+                int g0b = 0;
+                std::vector<uint64_t> wtmp(within_hist ? (size_t)ngroups * hist_len : 0), dtmp(nseq, 0), atmp(hist_len, 0);
+                for (size_t b = 0; b < batch_end.size() && ok2; ++b) {
+                    const int g1b = batch_end[b];
+                    std::vector<int> idx;
+                    for (int i = 0; i < nseq; ++i)
+                        if (group_of[i] >= g0b && group_of[i] < g1b) idx.push_back(i);
+                    std::vector<const uint8_t*> bs(idx.size());
+                    std::vector<uint64_t> bl(idx.size()), bd(idx.size(), 0);
+                    std::vector<int> bg(idx.size());
+                    for (size_t j = 0; j < idx.size(); ++j) { bs[j] = seqs[idx[j]]; bl[j] = lens[idx[j]]; bg[j] = group_of[idx[j]] - g0b; }
+                    bool done = false;
+                    KHCHK(exp1_skm(c, (int)idx.size(), bs.data(), bl.data(), on_device, bg.data(), g1b - g0b, k, cs,
+                                   within_hist ? wtmp.data() + (size_t)g0b * hist_len : nullptr, nullptr, hist_len, bd.data(), &done));
+                    if (!done) { ok2 = false; break; }
+                    for (size_t j = 0; j < idx.size(); ++j) dtmp[idx[j]] = bd[j];
+                    g0b = g1b;
+                }
+                if (ok2) {
+                    bool done = false;
+                    KHCHK(exp1_skm(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, nullptr, atmp.data(), hist_len, nullptr,
+                                   &done, /*by_group=*/true));
+                    ok2 = done;
+                }
+                if (ok2) {
+                    if (within_hist) memcpy(within_hist, wtmp.data(), 8 * wtmp.size());
+                    memcpy(across_hist, atmp.data(), 8 * (size_t)hist_len);
+                    if (distinct_per_seq) memcpy(distinct_per_seq, dtmp.data(), 8 * (size_t)nseq);
+                    return KH_OK;
+                }
+            }
             std::vector<kh_set*> asets;
             auto drop = [&]() { for (auto* s : asets) kh_set_free(s); asets.clear(); };
             bool ok = true;

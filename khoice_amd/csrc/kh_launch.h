@@ -138,6 +138,7 @@ constexpr u32 KH_SKM_CUR1_STRIDE = KH_TUNE_SKM_CUR1_STRIDE;
 struct KhSkmJob {
     const KhSeg* segs;
     const KhTile* tiles;
+    const u8* seg_tag;              // [nseg] tag of a segment's records; nullptr: the segment number (operand = genome)
     uint4* reg1;                    // [nb1][cap1] records by coarse bucket
     uint4* reg2;                    // [nslots][cap2] records by slot
     u32* cur1;                      // [nb1 * KH_SKM_CUR1_STRIDE] zeroed: cursor of bucket b at b * KH_SKM_CUR1_STRIDE

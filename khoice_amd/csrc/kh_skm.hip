@@ -89,6 +89,7 @@ __global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatt
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const KhTile t = jb.tiles[blockIdx.x];
     const KhSeg sg = jb.segs[t.seg];
+    const u32 rtag = jb.seg_tag ? jb.seg_tag[t.seg] : t.seg;   // the tag of the tile's records: the genome, or its group
     const int k = jb.k, m = jb.m;
     const u32 nslots = jb.nslots, S = jb.S, nmax = jb.nmax;
     const u64 smagic = ((1ull << 40) + S - 1) / S;   // slot / S == (slot * smagic) >> 40 for slot < 2^20
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(SKM_NT, KH_TUNE_SKM_SCATTER_WAVES) void k_skm_scatt
                         const u32 bits = 2 * (n + (u32)k - 1);
                         if (bits < 64) { rlo &= (1ull << bits) - 1ull; rhi = 0; }
                         else rhi &= kh_mask((int)bits - 64);
-                        rhi |= ((u64)fine << 44) | ((u64)t.seg << 53) | ((u64)n << 59);
+                        rhi |= ((u64)fine << 44) | ((u64)rtag << 53) | ((u64)n << 59);
                         L.stage[at] = make_uint4((u32)rlo, (u32)(rlo >> 32), (u32)rhi, (u32)(rhi >> 32));
                         L.sid[at] = (u16)coarse;
                         atomicAdd(&L.bcnt[coarse], 1u);

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(SKM_NT, 2) void k_skm2_scatter(const KhSkmJob jb) {
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const KhTile t = jb.tiles[blockIdx.x];
     const KhSeg sg = jb.segs[t.seg];
+    const u32 rtag = jb.seg_tag ? jb.seg_tag[t.seg] : t.seg;   // the tag of the tile's records: the genome, or its group
     const int k = jb.k, m = jb.m;
     const u32 nslots = jb.nslots, S = jb.S, nmax = jb.nmax;
     const u64 smagic = ((1ull << 40) + S - 1) / S;   // slot / S == (slot * smagic) >> 40 for slot < 2^20
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(SKM_NT, 2) void k_skm2_scatter(const KhSkmJob jb) {
                             const u32 wv = __builtin_amdgcn_alignbit(src[i + 1], src[i], r5);
                             out[i] = bits >= 32u * (i + 1) ? wv : (bits > 32u * i ? wv & ((1u << (bits - 32u * i)) - 1u) : 0u);
                         }
-                        out[7] |= (fine << 10) | (t.seg << 20) | (n << 26);
+                        out[7] |= (fine << 10) | (rtag << 20) | (n << 26);
                         L.stage[2 * at] = make_uint4(out[0], out[1], out[2], out[3]);
                         L.stage[2 * at + 1] = make_uint4(out[4], out[5], out[6], out[7]);
                         L.sid[at] = (u16)coarse;
@@ -312,7 +313,7 @@ constexpr u32 SKM2_UNT = KH_TUNE_SKM2_UNT, SKM2_UT = 2048, SKM2_UE = SKM2_UT / S
 constexpr u32 SKM2_UNW = SKM2_UNT / 64;
 constexpr u32 SKM2_URPT = 1024 / SKM2_UNT;         // records per thread when the slot is read: cap2 <= 1024
 constexpr u32 SKM2_SPEC = 320;                     // records of a slot read before their number is known
-constexpr u32 SKM2_OWN = 2048;                     // chunk owners: a slot of up to SKM2_UE * 2048 k-mer instances
+constexpr u32 SKM2_OWN = 8192;                     // chunk owners: a slot of up to SKM2_UE * 8192 k-mer instances (a block shared by a hundred genomes lands in few slots)
 size_t kh_skm2_union_lds_bytes(u32 nbins) {
     return (size_t)SKM2_UT * 24 + (size_t)SKM2_UT2 * 24 + 256 + 128 + 256 + (((size_t)nbins * 32 + 15) & ~(size_t)15) +
            (size_t)(SKM2_URPT * SKM2_UNT + 8) * 2 + (size_t)SKM2_OWN * 2;

@@ -185,7 +185,7 @@ def test_cfg2_full_size_other_k_super_kmer_form(eng, k):
 @pytest.mark.parametrize("k", [31, 41])
 def test_cfg3_full_size_10x10x5mbp(eng, k):
     """BASELINE configs[2] at its stated size: 10 species x 10 genomes x 5 Mbp (100 genomes: the
-    fused path runs it as batches of whole groups) — step_4 and step_8 histograms and the
+    fused path runs it as batches of whole groups plus one pass whose records carry the group number) — step_4 and step_8 histograms and the
     per-genome distinct counts against the C restatement, plus the reference's invariants."""
     from khoice_amd import synth
     from oracle import c_oracle as CO
@@ -193,9 +193,9 @@ def test_cfg3_full_size_10x10x5mbp(eng, k):
     seqs = [t for _, _, t in items]
     group_of = [s - 1 for s, _, _ in items]
     eng.profile(True)
-    before = eng.stats()["kernels"]["union_tagged"]["launches"]
+    before = eng.stats()["kernels"]["skm_union"]["launches"]
     got = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=5001)
-    assert eng.stats()["kernels"]["union_tagged"]["launches"] - before == 2      # two batches of groups
+    assert eng.stats()["kernels"]["skm_union"]["launches"] - before == 3         # two batches of groups + the pass by group
     eng.profile(False)
     want = CO.exp1(seqs, group_of, k, cs=5000, hist_len=5001)
     assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()

@@ -229,8 +229,22 @@ def test_skm_more_than_64_genomes_without_across_step(eng):
         assert ran == 2                                   # 6 groups (60 genomes) + 1 group
         assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
         assert (got["within_hist"] == want["within_hist"]).all()
-        full = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64)      # with the across-group step: key arrays
-        assert (full["within_hist"] == want["within_hist"]).all() and (full["across_hist"] == want["across_hist"]).all()
+        # with the across-group step: the two batches, then one more pass whose records carry the GROUP number
+        eng.profile(True)
+        before = skm_launches(eng)
+        full = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64)
+        ran = skm_launches(eng) - before
+        eng.profile(False)
+        assert ran == 3
+        same(full, want)
+        os.environ["KHOICE_NO_SKM_TWO_PASS"] = "1"      # and the key-array batches with emitted sets
+        try:
+            same(eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=64), want)
+        finally:
+            del os.environ["KHOICE_NO_SKM_TWO_PASS"]
+    # saturation and a short histogram through the two-pass form
+    want = CO.exp1(seqs, group_of, 31, cs=2, hist_len=4)
+    same(eng.exp1_run(seqs, group_of, 31, cs=2, hist_len=4), want)
 
 
 def test_skm_overfull_slot_rounds(eng):
