@@ -1649,20 +1649,19 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     const size_t off_ctl = 8 * hist_words, off_inst = off_ctl + 32, off_dup = off_inst + 8 * (size_t)nseq,
                  off_cur1 = off_dup + 8 * 64, off_cur2 = off_cur1 + 4 * (size_t)KH_SKM_CUR1_STRIDE * nb1,
                  off_ginfo = off_cur2 + 4 * (size_t)((nslots + 3) & ~3u), off_tags = off_ginfo + 256,
-                 ws_bytes = off_tags + (((size_t)nseq + 15) & ~(size_t)15);
-    Tmp d_seq, d_segs, d_tiles, d_ws, d_reg1, d_reg2;
+                 off_segs = off_tags + (((size_t)nseq + 15) & ~(size_t)15), off_tiles = off_segs + sizeof(KhSeg) * nseq,
+                 ws_bytes = off_tiles + sizeof(KhTile) * (size_t)std::max<u32>(1, ntiles);   // [ginfo .. tiles]: one upload
+    Tmp d_seq, d_ws, d_reg1, d_reg2;
     bool need_pack = false;
     for (int i = 0; i < nseq; ++i)
         if (!(on_device && (reinterpret_cast<uintptr_t>(seqs[perm[i]]) & 15) == 0)) need_pack = true;
     TMP_ALLOC(d_seq, c, need_pack ? seq_bytes : 256);
-    TMP_ALLOC(d_segs, c, sizeof(KhSeg) * nseq);
-    TMP_ALLOC(d_tiles, c, sizeof(KhTile) * std::max<u32>(1, ntiles));
     TMP_ALLOC(d_ws, c, ws_bytes);
     TMP_ALLOC(d_reg1, c, reg1_bytes);
     TMP_ALLOC(d_reg2, c, reg2_bytes);
     struct PinG { kh_ctx* c; void* p = nullptr; size_t n = 0; ~PinG() { if (p) c->pin_release(p, n); } } pin{c};
     // pinned staging: [segs][tiles][ginfo] up, [hist .. dup] down
-    const size_t up_bytes = sizeof(KhSeg) * nseq + sizeof(KhTile) * (size_t)ntiles + 256 + (((size_t)nseq + 15) & ~(size_t)15);
+    const size_t up_bytes = ws_bytes - off_ginfo;   // the upload, laid out as on the device
     const size_t down_bytes = off_cur1;
     pin.p = c->pin_alloc(up_bytes + down_bytes + 64, &pin.n);
     if (!pin.p) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
@@ -1677,12 +1676,12 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         HIPCHK(hipMemcpyAsync(d_seq.as<u8>() + pack_off[i], src, segs[i].len,
                               on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
-    KhSeg* h_segs = reinterpret_cast<KhSeg*>(h_up);
-    KhTile* h_tiles = reinterpret_cast<KhTile*>(h_up + sizeof(KhSeg) * nseq);
-    u32* h_ginfo = reinterpret_cast<u32*>(h_up + sizeof(KhSeg) * nseq + sizeof(KhTile) * (size_t)ntiles);
+    u32* h_ginfo = reinterpret_cast<u32*>(h_up);
+    u8* h_tags = h_up + (off_tags - off_ginfo);
+    KhSeg* h_segs = reinterpret_cast<KhSeg*>(h_up + (off_segs - off_ginfo));
+    KhTile* h_tiles = reinterpret_cast<KhTile*>(h_up + (off_tiles - off_ginfo));
     memcpy(h_segs, segs.data(), sizeof(KhSeg) * nseq);
     if (ntiles) memcpy(h_tiles, tiles.data(), sizeof(KhTile) * (size_t)ntiles);
-    u8* h_tags = reinterpret_cast<u8*>(h_ginfo + 64);
     memset(h_ginfo, 0, 256);
     if (by_group) {
         for (int g = 0; g < ngroups; ++g) h_ginfo[g] = (u32)g | (1u << 8) | (bin0[g] << 16);
@@ -1692,17 +1691,15 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
             for (int j = 0; j < gsize[g]; ++j)
                 h_ginfo[gstart[g] + j] = (u32)gstart[g] | ((u32)gsize[g] << 8) | (bin0[g] << 16);
     }
-    HIPCHK(hipMemcpyAsync(d_segs.b->p, h_segs, sizeof(KhSeg) * nseq, hipMemcpyHostToDevice, st));
-    if (ntiles) HIPCHK(hipMemcpyAsync(d_tiles.b->p, h_tiles, sizeof(KhTile) * (size_t)ntiles, hipMemcpyHostToDevice, st));
     u8* wsp = d_ws.as<u8>();
     HIPCHK(hipMemsetAsync(wsp, 0, off_ginfo, st));
-    HIPCHK(hipMemcpyAsync(wsp + off_ginfo, h_ginfo, 256 + (by_group ? (size_t)nseq : 0), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(wsp + off_ginfo, h_up, up_bytes, hipMemcpyHostToDevice, st));
     c->prof_end();
 
     KhSkmJob job;
     job.seg_tag = by_group ? wsp + off_tags : nullptr;
-    job.segs = d_segs.as<KhSeg>();
-    job.tiles = d_tiles.as<KhTile>();
+    job.segs = reinterpret_cast<const KhSeg*>(wsp + off_segs);
+    job.tiles = reinterpret_cast<const KhTile*>(wsp + off_tiles);
     job.reg1 = d_reg1.as<uint4>();
     job.reg2 = d_reg2.as<uint4>();
     job.cur1 = reinterpret_cast<u32*>(wsp + off_cur1);

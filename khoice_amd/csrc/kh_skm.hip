@@ -10,13 +10,14 @@
 //                   a k-mer (the minimizer) -> slot = f(minimizer).  A k-mer and its reverse complement
 //                   have the same canonical m-mers, hence the same slot; consecutive k-mers mostly share
 //                   their minimizer, so a run of n of them travels as ONE 16-byte record (n + k - 1 bases
-//                   at two bits, genome tag, n): ~2 bytes per k-mer instead of 8.  Records are counting-
-//                   sorted by coarse bucket in LDS and flushed as runs (one global atomic per run).
+//                   at two bits, genome tag, n; a run may go on into the next thread's positions): ~2 bytes
+//                   per k-mer instead of 8.  2048 records are counting-sorted by coarse bucket in LDS and
+//                   flushed as runs (one global atomic per run, cursors on separate memory channels).
 //   k_skm_regroup   one workgroup per coarse bucket, 8192 records per round: the same LDS counting sort by
 //                   fine slot (cursors in LDS: the workgroup owns its slots) -> every slot of the key space
 //                   is one contiguous record range.
-//   k_skm_union     one workgroup per slot: records -> k-mers (balanced: a thread takes 8 consecutive
-//                   k-mer indices of the slot, whatever records they fall in) -> canonical key -> LDS hash
+//   k_skm_union     one workgroup of 1024 threads per slot: records -> k-mers (balanced: a thread takes 4
+//                   consecutive k-mer indices of the slot, whatever records they fall in) -> canonical key -> LDS hash
 //                   set {key, genome mask} -> popcount per group / number of groups -> histogram bins.
 //                   A repeated (key, genome) pair is seen when its mask bit is already set: distinct
 //                   k-mers of a genome = its valid k-mer instances - those repeats.
@@ -347,9 +348,9 @@ __global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm_regroup(const KhSkmJob jb)
 // S2b: one slot per workgroup -> LDS hash set {canonical k-mer, genome mask} -> histogram bins.
 //
 // Records -> k-mers: a block scan of the records' k-mer counts numbers the slot's k-mers, and every thread
-// expands 8 CONSECUTIVE k-mer indices whatever records they fall in (chunk -> record table in LDS, the
+// expands SKM_UE (4) CONSECUTIVE k-mer indices whatever records they fall in (chunk -> record table in LDS, the
 // records themselves re-read from L2): balanced lanes.
-// Insertion: rounds of 8 compare-and-swaps per thread.  A key gets KH_HASH_ROUNDS probes in the main table,
+// Insertion: rounds of SKM_UE compare-and-swaps per thread.  A key gets KH_HASH_ROUNDS probes in the main table,
 // moves to a small second table with an independent hash, and from a full second table back to unbounded
 // probing of the main one; occupied entries stay occupied, so every copy of a key takes the same decisions as
 // the first.  (Measured and rejected: finishing the keys that lost round 1 one per lane in a loop — fewer
