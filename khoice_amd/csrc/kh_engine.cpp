@@ -479,10 +479,8 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     const u32 nb_alloc = (max_nb + 3) & ~3u;
 
     // ---- device buffers
-    Tmp d_seq, d_segs, d_tiles, d_thist, d_tot, d_bstart, d_part, d_lb;
+    Tmp d_seq, d_thist, d_tot, d_bstart, d_part, d_lb;
     TMP_ALLOC(d_seq, c, seq_bytes);
-    TMP_ALLOC(d_segs, c, sizeof(KhSeg) * nseq);
-    TMP_ALLOC(d_tiles, c, sizeof(KhTile) * std::max<u32>(1, ntiles));
     TMP_ALLOC(d_thist, c, 4 * std::max<u64>(1, thist_n));
     TMP_ALLOC(d_tot, c, 8 * (u64)nb_total);
     TMP_ALLOC(d_bstart, c, 8 * ((u64)nb_total + 1));
@@ -540,9 +538,6 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         HIPCHK(hipMemcpyAsync(d_seq.as<u8>() + pack_off[i], seqs[i], lens[i],
                               on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
-    HIPCHK(hipMemcpyAsync(d_segs.b->p, segs.data(), sizeof(KhSeg) * nseq, hipMemcpyHostToDevice, st));
-    if (ntiles)
-        HIPCHK(hipMemcpyAsync(d_tiles.b->p, tiles.data(), sizeof(KhTile) * ntiles, hipMemcpyHostToDevice, st));
     // Start order of pass C (KhBucketWork): buckets of up to 64 consecutive segments are
     // interleaved (bucket 0 of each, bucket 1 of each, ...), every segment writes into its own
     // output region [out_base, out_base + npos) and runs its own look-back chain.
@@ -550,10 +545,17 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         kh_ctx* c; void* p = nullptr; size_t bytes = 0;
         ~Pin() { if (p) c->pin_release(p, bytes); }
     } plan_pin{c};
-    plan_pin.p = c->pin_alloc(4 * (size_t)nb_total + 8 * (size_t)nseq, &plan_pin.bytes);
+    // the launch sequence's small tables — output bases, start ranks, segments, tiles — travel in ONE upload
+    // (three separate copies, two of them from pageable vectors, were a sixth of a single-genome build)
+    const size_t up_rank = 8 * (size_t)nseq, up_segs = (up_rank + 4 * (size_t)nb_total + 7) & ~(size_t)7,
+                 up_tiles = up_segs + sizeof(KhSeg) * (size_t)nseq,
+                 up_bytes = up_tiles + sizeof(KhTile) * (size_t)std::max<u32>(1, ntiles);
+    plan_pin.p = c->pin_alloc(up_bytes, &plan_pin.bytes);
     if (!plan_pin.p) return kh_fail(KH_E_NOMEM, "pinned host allocation failed");
     u64* h_out_base = static_cast<u64*>(plan_pin.p);
     u32* h_rank = reinterpret_cast<u32*>(h_out_base + nseq);
+    memcpy(static_cast<u8*>(plan_pin.p) + up_segs, segs.data(), sizeof(KhSeg) * (size_t)nseq);
+    if (ntiles) memcpy(static_cast<u8*>(plan_pin.p) + up_tiles, tiles.data(), sizeof(KhTile) * (size_t)ntiles);
     {
         u64 ob = 0;
         u32 next = 0;
@@ -568,27 +570,29 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
         }
     }
     Tmp d_plan, d_work;
-    TMP_ALLOC(d_plan, c, 4 * (size_t)nb_total + 8 * (size_t)nseq);
+    TMP_ALLOC(d_plan, c, up_bytes);
     TMP_ALLOC(d_work, c, sizeof(KhBucketWork) * (size_t)nb_total);
-    HIPCHK(hipMemcpyAsync(d_plan.b->p, plan_pin.p, 4 * (size_t)nb_total + 8 * (size_t)nseq, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_plan.b->p, plan_pin.p, up_bytes, hipMemcpyHostToDevice, st));
     const u64* d_out_base = d_plan.as<u64>();
     const u32* d_rank = reinterpret_cast<const u32*>(d_out_base + nseq);
+    const KhSeg* d_segs_p = reinterpret_cast<const KhSeg*>(d_plan.as<u8>() + up_segs);
+    const KhTile* d_tiles_p = reinterpret_cast<const KhTile*>(d_plan.as<u8>() + up_tiles);
     c->prof_end();
 
     // ---- pass A, bucket plan, pass B
     c->prof_begin(KC_EXTRACT_HIST);
-    kh_launch_extract(W, false, d_seq.as<u8>(), d_segs.as<KhSeg>(), d_tiles.as<KhTile>(), ntiles,
+    kh_launch_extract(W, false, d_seq.as<u8>(), d_segs_p, d_tiles_p, ntiles,
                       nb_alloc, k, d_thist.as<u32>(), nullptr, nullptr, tile_pos, st);
     c->prof_end();
     c->prof_begin(KC_BUCKET_PLAN);
-    kh_launch_col_totals(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_tot.as<u64>(), st);
+    kh_launch_col_totals(d_segs_p, nseq, max_nb, d_thist.as<u32>(), d_tot.as<u64>(), st);
     kh_launch_exscan(d_tot.as<u64>(), d_bstart.as<u64>(), nb_total, d_scan.as<u64>(), st);
     Tmp d_over;   // grid mode: list of the buckets above the LDS capacity
     if (grid) {
         TMP_ALLOC(d_over, c, 4 * ((size_t)nb_total + 1));
         HIPCHK(hipMemsetAsync(d_over.b->p, 0, 4, st));
     }
-    kh_launch_col_offsets(d_segs.as<KhSeg>(), nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(), d_rank,
+    kh_launch_col_offsets(d_segs_p, nseq, max_nb, d_thist.as<u32>(), d_bstart.as<u64>(), d_rank,
                           d_out_base, d_work.as<KhBucketWork>(), grid ? d_over.as<u32>() : nullptr,
                           grid ? kh_grid_bucket_capacity(W) : 0u, st);
     c->prof_end();
@@ -608,7 +612,7 @@ static int build_once(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     kh_debug_set_stamps(d_stamps_b.as<u64>());
 #endif
     c->prof_begin(KC_EXTRACT_SCATTER);
-    kh_launch_extract(W, true, d_seq.as<u8>(), d_segs.as<KhSeg>(), d_tiles.as<KhTile>(), ntiles,
+    kh_launch_extract(W, true, d_seq.as<u8>(), d_segs_p, d_tiles_p, ntiles,
                       nb_alloc, k, d_thist.as<u32>(), d_bstart.as<u64>(), d_part.b->p, tile_pos, st);
     c->prof_end();
 #ifdef KH_STAMPS
