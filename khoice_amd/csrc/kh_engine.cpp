@@ -1582,17 +1582,35 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     // group put their copies of a locus in the same slot, a minimizer run at a time: clumps of c = (w + 1) / 2 x
     // (largest group) instances, so sigma = sqrt(mean x c); mean + 2.5 sigma = T  (measured: 2500 / 2900 / 3200 /
     // 3500 / 3800 at k = 31 with groups of five: union 1.96 / 1.81 / 1.75 / 1.80 / 1.94 ms; the rule gives 3180)
+    // entries of the union's hash set (one-word keys): 4096 with 1024 threads (two workgroups per CU) or 2048 with 512
+    // (four per CU, half-size slots)
+    u32 table = 4096;
+    if (const char* e = getenv("KHOICE_SKM_TABLE")) table = atoi(e) == 2048 ? 2048u : 4096u;
     u32 mean;
     double clump = 1.0;   // instances that land in a slot together
     {
         u32 fan = 1;
         for (int g = 0; g < ngroups; ++g) fan = std::max<u32>(fan, (u32)gsize[g]);
-        const double T = two ? (double)kh_skm2_table() : 4096.0, cl = 0.5 * (double)(w + 1) * (double)fan;
+        const double T = two ? (double)kh_skm2_table() : (double)table, cl = 0.5 * (double)(w + 1) * (double)fan;
         const double r = 0.5 * (-2.5 * std::sqrt(cl) + std::sqrt(6.25 * cl + 4.0 * T));
         mean = (u32)std::max(256.0, r * r);
         clump = cl;
     }
     if (const char* e = getenv("KHOICE_SKM_MEAN")) mean = std::max<u32>(64, (u32)strtoul(e, nullptr, 10));
+    // records: a run of k-mers with one minimizer is (w + 1) / 2 long on average; cuts at the waves' 2048
+    // positions, at boundaries a run may not cross (a second thread boundary, nmax) and at invalid bases add
+    // a little (measured: 0.120 records per k-mer at w = 16, 0.27 at w = 7)
+    const double per_kmer = 2.0 / (double)(w + 1) + 1.0 / 48.0;
+    // a slot's records vary like its instances: sigma / mean = sqrt(clump / mean) (12 % at k = 31 with groups of five,
+    // 36 % with ten genomes per group and two-word keys): five sigma, at least 1.7
+    double slack1 = 1.25, slack2 = 1.7;
+    const u32 max_cap2 = two ? kh_skm2_max_cap2() : kh_skm_union_max_cap2(table);
+    for (int it = 0; it < 8; ++it) {   // short windows (k = 20 .. 22: 3.5 k-mers per record): fewer instances per slot so that its records fit
+        slack2 = std::max(1.7, 1.0 + 5.0 * std::sqrt(clump / (double)mean));
+        const double c2 = (double)mean * per_kmer * slack2 + 96 + 16;
+        if (c2 <= (double)max_cap2 || mean <= 256) break;
+        mean = std::max<u32>(256, (u32)((double)mean * (double)max_cap2 / c2 * 0.98));
+    }
     const u64 nslots64 = std::max<u64>(1, (total_pos + mean - 1) / mean);
     // coarse buckets: 256 keep the scatter's runs long; inputs past 256 x 512 slots (> 400 M k-mers) take 512
     const u32 max_coarse = (two || nslots64 > (u64)KH_SKM_MAX_COARSE * KH_SKM_MAX_FINE) ? KH_SKM2_MAX_COARSE : KH_SKM_MAX_COARSE;
@@ -1600,18 +1618,11 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     const u32 nslots = (u32)nslots64;
     const u32 S = std::max<u32>(1, (nslots + max_coarse - 1) / max_coarse);
     const u32 nb1 = (nslots + S - 1) / S;
-    // records: a run of k-mers with one minimizer is (w + 1) / 2 long on average; cuts at the waves' 2048
-    // positions, at boundaries a run may not cross (a second thread boundary, nmax) and at invalid bases add
-    // a little (measured: 0.120 records per k-mer at w = 16, 0.27 at w = 7)
-    const double per_kmer = 2.0 / (double)(w + 1) + 1.0 / 48.0;
     const double recs = (double)total_pos * per_kmer;
-    // a slot's records vary like its instances: sigma / mean = sqrt(clump / mean) (12 % at k = 31 with groups of five,
-    // 36 % with ten genomes per group and two-word keys): five sigma, at least 1.7
-    double slack1 = 1.25, slack2 = std::max(1.7, 1.0 + 5.0 * std::sqrt(clump / (double)mean));
     if (const char* e = getenv("KHOICE_SKM_SLACK")) slack1 = slack2 = std::max(0.01, atof(e));   // below 1: tests of the overflow fall-back
     const u64 cap1_64 = ((u64)(recs / nb1 * slack1) + 2048 + 63) & ~63ull;
     const u64 cap2_64 = ((u64)(recs / nslots * slack2) + 96 + 15) & ~15ull;
-    if (cap2_64 > (two ? kh_skm2_max_cap2() : KH_SKM_MAX_CAP2) || cap1_64 > 0x7fffffffull) return KH_OK;
+    if (cap2_64 > max_cap2 || cap1_64 > 0x7fffffffull) return KH_OK;
     const u32 cap1 = (u32)cap1_64, cap2 = (u32)cap2_64;
     const size_t rec_bytes = two ? 32 : 16;
     const size_t reg1_bytes = rec_bytes * (size_t)nb1 * cap1, reg2_bytes = rec_bytes * (size_t)nslots * cap2;
@@ -1717,6 +1728,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     job.k = k; job.m = m; job.w = w; job.nmax = nmax;
     job.nslots = nslots; job.S = S; job.nb1 = nb1; job.cap1 = cap1; job.cap2 = cap2;
     job.nbins = nbins; job.abase = abase; job.reps = reps; job.nops = by_group ? (u32)ngroups : (u32)nseq;
+    job.table = table;
 #ifdef KH_STAMPS
     Tmp d_stamps;
     const u64 nst = std::max<u64>(ntiles, nslots);
@@ -1753,15 +1765,17 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         std::vector<u32> h1(nb1), h2(nslots);
         HIPCHK(hipMemcpy2DAsync(h1.data(), 4, job.cur1, 4 * (size_t)KH_SKM_CUR1_STRIDE, 4, nb1, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(h2.data(), job.cur2, 4 * (size_t)nslots, hipMemcpyDeviceToHost, st));
+        u32 hc[8];
+        HIPCHK(hipMemcpyAsync(hc, job.ctl, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         u64 t1 = 0, t2 = 0;
         u32 m1 = 0, m2 = 0;
         for (u32 v : h1) { t1 += v; m1 = std::max(m1, v); }
         for (u32 v : h2) { t2 += v; m2 = std::max(m2, v); }
         fprintf(stderr, "[skm] k=%d m=%d w=%u nmax=%u positions=%llu records=%llu (%.2f k-mers each) nb1=%u S=%u nslots=%u | "
-                        "coarse: mean %.0f max %u cap %u | slot: mean %.1f max %u cap %u | tiles %u x %u\n",
+                        "coarse: mean %.0f max %u cap %u | slot: mean %.1f max %u cap %u | tiles %u x %u | expanded: %u k-mers\n",
                 k, m, w, nmax, (unsigned long long)total_pos, (unsigned long long)t1, (double)total_pos / std::max<u64>(1, t1),
-                nb1, S, nslots, (double)t1 / nb1, m1, cap1, (double)t2 / nslots, m2, cap2, ntiles, tile_pos);
+                nb1, S, nslots, (double)t1 / nb1, m1, cap1, (double)t2 / nslots, m2, cap2, ntiles, tile_pos, hc[3]);
     }
     HIPCHK(hipMemcpyAsync(h_down, wsp, down_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -127,7 +127,7 @@ struct KhTagJob {
 constexpr u32 KH_SKM_STAGE = KH_TUNE_SKM_STAGE;   // records counting-sorted in LDS per flush of the scatter
 constexpr u32 KH_SKM_MAX_COARSE = 256;    // coarse buckets (LDS counters of the scatter); 512 (KH_SKM2_MAX_COARSE) for inputs too large for 256
 constexpr u32 KH_SKM_MAX_FINE = 512;      // slots per coarse bucket (9 bits in the record)
-constexpr u32 KH_SKM_MAX_CAP2 = 2048;     // records of one slot (the union reads four per thread)
+constexpr u32 KH_SKM_MAX_CAP2 = 1024;     // records of one slot with one-word keys: one per thread of the union (512 with the 2048-entry table)
 constexpr int KH_SKM_MIN_K = 20, KH_SKM_MAX_K = 32;
 #ifndef KH_TUNE_SKM_CUR1_STRIDE
 #define KH_TUNE_SKM_CUR1_STRIDE 1088
@@ -154,11 +154,13 @@ struct KhSkmJob {
     u32 nmax;                       // k-mers per record at most
     u32 nslots, S, nb1, cap1, cap2;
     u32 nbins, abase, reps, nops;
+    u32 table;                      // entries of the union's hash set: 4096 (1024 threads) or 2048 (512 threads); one-word keys
 };
 bool kh_skm_supports_w(u32 w);   // m-mers per k-mer the scatter kernel is instantiated for
 size_t kh_skm_scatter_lds_bytes(u32 nb1);
 size_t kh_skm_regroup_lds_bytes(u32 S);
-size_t kh_skm_union_lds_bytes(u32 nbins);
+size_t kh_skm_union_lds_bytes(u32 table);
+u32 kh_skm_union_max_cap2(u32 table);   // records of a slot the union with that table takes
 void kh_launch_skm_scatter(const KhSkmJob& job, u32 ntiles, hipStream_t st);
 void kh_launch_skm_regroup(const KhSkmJob& job, hipStream_t st);
 void kh_launch_skm_union(const KhSkmJob& job, u32 cs, hipStream_t st);

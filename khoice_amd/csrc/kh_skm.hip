@@ -44,17 +44,14 @@ void kh_debug_set_stamps_skm(u64* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_skm_
 #define SKM_STAMP(idx) do {} while (0)
 #endif
 
-#ifndef KH_TUNE_SKM_UNT
-#define KH_TUNE_SKM_UNT 1024    // threads of a union workgroup: two of them per CU = 8 waves per SIMD (512: 2.27 ms against 1.89)
+// ISA study only (-DKH_MARKS with --cuda-device-only -S): comments that delimit the sections of the union in the assembly
+#ifdef KH_MARKS
+#define SKM_MARK(name) asm volatile("; ===== MARK " name ::: "memory")
+#else
+#define SKM_MARK(name) do {} while (0)
 #endif
 #ifndef KH_TUNE_SKM_FULL_ROUNDS
 #define KH_TUNE_SKM_FULL_ROUNDS KH_TUNE_HASH_ROUNDS   // probe rounds made by all keys of a thread together; the rest one key per lane
-#endif
-#ifndef KH_TUNE_SKM_PREFETCH
-#define KH_TUNE_SKM_PREFETCH 1   // union: the record behind the current one waits in registers (1.741 -> 1.725 ms; fits the 64 VGPRs since the addresses of the read-out are formed late)
-#endif
-#ifndef KH_TUNE_SKM_OVF_SERIAL
-#define KH_TUNE_SKM_OVF_SERIAL 1
 #endif
 #ifndef KH_TUNE_SKM_SCATTER_PREFETCH
 #define KH_TUNE_SKM_SCATTER_PREFETCH 0   // 1: the next sub-tile's bases wait in registers while this one is processed (0.656 ms against 0.624: three workgroups per CU hide the load as well, with fewer registers)
@@ -347,329 +344,398 @@ __global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm_regroup(const KhSkmJob jb)
 // ------------------------------------------------------------------------------------------
 // S2b: one slot per workgroup -> LDS hash set {canonical k-mer, genome mask} -> histogram bins.
 //
-// Records -> k-mers: a block scan of the records' k-mer counts numbers the slot's k-mers, and every thread
-// expands SKM_UE (4) CONSECUTIVE k-mer indices whatever records they fall in (chunk -> record table in LDS, the
-// records themselves re-read from L2): balanced lanes.
-// Insertion: rounds of SKM_UE compare-and-swaps per thread.  A key gets KH_HASH_ROUNDS probes in the main table,
-// moves to a small second table with an independent hash, and from a full second table back to unbounded
-// probing of the main one; occupied entries stay occupied, so every copy of a key takes the same decisions as
-// the first.  (Measured and rejected: finishing the keys that lost round 1 one per lane in a loop — fewer
-// instructions, but a chain of ~20 dependent LDS round trips per wave: 2.63 ms against 2.30.)
+// 1. Identical records are expanded ONCE.  A record is a content-defined piece of sequence (a run of k-mers with
+//    one minimizer), so the genomes of a species hold the same records wherever they agree: the slot's records
+//    (one per thread) meet in a small LDS hash set keyed by their bases; a record that finds its own content
+//    already there ORs its genome bit into the first one's mask and retires (a copy inside the SAME genome: all
+//    its k-mers are repeats).  Related genomes (the workload the reference is written for: groups of one species)
+//    halve the k-mers that reach the big table; unrelated ones lose one LDS round trip.
+// 2. Records -> k-mers: every surviving record is cut into chunks of 4 consecutive k-mers, a scan numbers the
+//    chunks, a thread takes one chunk: first k-mer by a funnel shift + reversal of the 2-bit groups, the other
+//    three by ROLLING both strands (32-bit halves: a funnel shift and a shift-or each); the keys of a thread share
+//    one genome mask.
+// 3. Insertion: rounds of 4 compare-and-swaps per thread.  A key gets KH_HASH_ROUNDS probes in the main table,
+//    moves to a small second table with an independent hash, and from a full second table back to unbounded
+//    probing of the main one; occupied entries stay occupied, so every copy of a key takes the same decisions as
+//    the first.  (Measured and rejected: finishing the keys that lost round 1 one per lane in a loop — fewer
+//    instructions, but a chain of ~20 dependent LDS round trips per wave: 2.63 ms against 2.30.)
+// 4. Read-out: the thread whose compare-and-swap CREATED an entry remembers where; once all masks are final it
+//    turns its own entries into histogram bins (popcount per group / number of groups).  Nobody scans the table,
+//    no key is read again, waves without chunks have nothing to do.
+//
+// Geometry <NT, T>: threads and table entries of a workgroup.  <1024, 4096>: 79 KB of LDS, two workgroups per CU;
+// <512, 2048>: 40 KB, four per CU (half-size slots: twice as many independent barrier chains per CU).
 // ------------------------------------------------------------------------------------------
-constexpr u32 SKM_UNT = KH_TUNE_SKM_UNT, SKM_UT = 4096, SKM_UE = SKM_UT / SKM_UNT, SKM_UT2 = 256;
-constexpr u32 SKM_UNW = SKM_UNT / 64;             // waves
-constexpr u32 SKM_URPT = 2048 / SKM_UNT;           // records per thread when the slot is read: cap2 <= 2048
-constexpr u32 SKM_SPEC = 576;                     // records of a slot read before their number is known (mean ~420)
-constexpr u32 SKM_OWN = 2048;                     // chunk owners: a slot of up to SKM_UE * 2048 k-mer instances
-size_t kh_skm_union_lds_bytes(u32 nbins) {
-    return (size_t)SKM_UT * 16 + (size_t)SKM_UT2 * 16 + 256 + 128 + 256 + (((size_t)nbins * 32 + 15) & ~(size_t)15) +
-           (size_t)(SKM_URPT * SKM_UNT + 8) * 2 + (size_t)SKM_OWN * 2;
-}
+#ifndef KH_TUNE_SKM_UE
+#define KH_TUNE_SKM_UE 2
+#endif
+constexpr u32 SKM_UE = KH_TUNE_SKM_UE;                // k-mers per chunk (2 or 4)
+constexpr u32 SKM_OB = SKM_UE == 2 ? 4 : 3;           // bits of a chunk's number inside its record (n <= 31)
+constexpr u32 SKM_PASSES = SKM_UE == 2 ? 4 : 2;       // chunks of a slot: at most SKM_PASSES per thread
+constexpr u32 SKM_HSTRIPE_WORDS = 288;                // histogram copies in LDS: 4 / 2 / 1 per bin for <= 72 / 144 / 255 bins
+template <u32 NT, u32 T> struct SkmUnionGeo {
+    static constexpr u32 T2 = T / 32;                 // second table
+    static constexpr u32 MAXREC = NT;                 // records of a slot (cap2 <= this): one per thread
+    static constexpr u32 MAXCH = SKM_PASSES * NT;     // chunks of a slot (after the merge of identical records)
+    static constexpr u32 HBITS = T == 4096 ? 12 : (T == 2048 ? 11 : 10);
+    static constexpr size_t LDS = (size_t)T * 16 + (size_t)T2 * 16 + 256 + 128 + 256 + (size_t)SKM_HSTRIPE_WORDS * 4 +
+                                  (size_t)MAXCH * 2 + (size_t)MAXREC * 4;
+    static_assert(MAXREC * 16 <= T * 8, "records are staged in the key plane");
+    static_assert(T2 <= NT && T / 4 <= NT, "clears are one store per thread");
+};
+u32 kh_skm_union_threads(u32 table) { return table == 2048 ? 512u : 1024u; }
+u32 kh_skm_union_max_cap2(u32 table) { return kh_skm_union_threads(table); }
+size_t kh_skm_union_lds_bytes(u32 table) { return table == 2048 ? SkmUnionGeo<512, 2048>::LDS : SkmUnionGeo<1024, 4096>::LDS; }
 
-__device__ __forceinline__ u32 key_hash(u64 can) { return ((u32)can ^ (u32)(can >> 32)) * 0x9E3779B1u; }
+__device__ __forceinline__ u32 key_hash2(u32 lo, u32 hi) { return (lo ^ hi) * 0x9E3779B1u; }
 
-__global__ __launch_bounds__(SKM_UNT, 2 * (SKM_UNT / 64) / 4) void k_skm_union(const KhSkmJob jb, u32 cs) {
+template <u32 NT, u32 T>
+__global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
-    constexpr u32 NT = SKM_UNT, T = SKM_UT, T2 = SKM_UT2, HBITS = 12;
+    using G = SkmUnionGeo<NT, T>;
+    constexpr u32 T2 = G::T2, HBITS = G::HBITS, NW = NT / 64;
     constexpr int E = (int)SKM_UE;
     constexpr u64 EMPTY = ~0ull;   // never a canonical key: the reverse complement of the all-T k-mer is 0
     // Table planes: keys (8-byte stride), low and high halves of the genome masks (4-byte stride).
-    struct Tbl { unsigned long long* key; u32* mlo; u32* mhi; };
     u8* p = lds_raw;
-    Tbl tbl, ovf;
-    tbl.key = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T * 8;
-    tbl.mlo = reinterpret_cast<u32*>(p);                      p += (size_t)T * 4;
-    tbl.mhi = reinterpret_cast<u32*>(p);                      p += (size_t)T * 4;
-    ovf.key = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T2 * 8;
-    ovf.mlo = reinterpret_cast<u32*>(p);                      p += (size_t)T2 * 4;
-    ovf.mhi = reinterpret_cast<u32*>(p);                      p += (size_t)T2 * 4;
-    u32* ginfo = reinterpret_cast<u32*>(p);                   p += 256;
-    u32* scratch = reinterpret_cast<u32*>(p);                 p += 128;
-    u32* dupc = reinterpret_cast<u32*>(p);                    p += 256;
-    u32* hstripe = reinterpret_cast<u32*>(p);                 p += ((size_t)jb.nbins * 32 + 15) & ~(size_t)15;
-    u16* roff = reinterpret_cast<u16*>(p);                    p += (size_t)(SKM_URPT * NT + 8) * 2;   // first k-mer index of every record
-    u16* owner = reinterpret_cast<u16*>(p);                   // [SKM_OWN] record that holds k-mer index 8c
-    const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    const u32 nbins = jb.nbins, cap2 = jb.cap2;
+    unsigned long long* tkey = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T * 8;
+    u32* tmlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T * 4;
+    u32* tmhi = reinterpret_cast<u32*>(p);                                 p += (size_t)T * 4;
+    unsigned long long* okey = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T2 * 8;
+    u32* omlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
+    u32* omhi = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
+    u32* ginfo = reinterpret_cast<u32*>(p);                                p += 256;
+    u32* scratch = reinterpret_cast<u32*>(p);                              p += 128;
+    u32* dupc = reinterpret_cast<u32*>(p);                                 p += 256;
+    u32* hstripe = reinterpret_cast<u32*>(p);                              p += (size_t)SKM_HSTRIPE_WORDS * 4;
+    u16* owner = reinterpret_cast<u16*>(p);                                p += (size_t)G::MAXCH * 2;   // chunk -> record << 3 | chunk of the record
+    u32* rmask = reinterpret_cast<u32*>(p);                                // [MAXREC] genomes (of one half of the mask) that hold the record
+    // while identical records are merged the table is not in use yet: the records are staged in its key plane, the
+    // set of their contents (record number + 1, 0: empty) is its low mask plane
+    uint4* stage = reinterpret_cast<uint4*>(tkey);
+    u32* dd = tmlo;
+    const u32 tid = threadIdx.x, lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 nbins = jb.nbins;
     const int k = jb.k;
     const u32 slot = blockIdx.x;
-    const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2;
-    // ---- the slot's records, SKM_URPT consecutive ones per thread.  Their number is not known yet: the first
-    // SKM_SPEC (more than nearly every slot holds) are requested together with it, the others once it is
-    // (reading the whole region up to its capacity moved 2.5x the records' bytes).
-    const u32 have = jb.cur2[slot];
-    uint4 rr[SKM_URPT];
+    const u32 sshift = nbins <= 72u ? 2u : (nbins <= 144u ? 1u : 0u), smask = (1u << sshift) - 1u;
+    const uint4* __restrict__ reg = jb.reg2 + (u64)slot * jb.cap2;
+    // ---- the slot's records, one per thread; their number comes by a scalar load first: nothing is fetched that
+    // is not a record
+    u32 nrec = jb.cur2[slot];
+    nrec = nrec < jb.cap2 ? nrec : jb.cap2;
+    nrec = nrec < G::MAXREC ? nrec : G::MAXREC;
+    const uint4 rr = tid < nrec ? reg[tid] : make_uint4(0, 0, 0, 0);
+    auto clear_keys = [&]() {
+        uint4* k4 = reinterpret_cast<uint4*>(tkey);
 #pragma unroll
-    for (u32 j = 0; j < SKM_URPT; ++j) {
-        const u32 i = SKM_URPT * tid + j;
-        rr[j] = i < (cap2 < SKM_SPEC ? cap2 : SKM_SPEC) ? reg[i] : make_uint4(0, 0, 0, 0);
-    }
-    auto clear_tables = [&]() {
-        uint4* k4 = reinterpret_cast<uint4*>(tbl.key);    // T * 8 bytes of ones, then T * 8 bytes of zeros (both mask planes)
-        uint4* m4 = reinterpret_cast<uint4*>(tbl.mlo);
-#pragma unroll
-        for (int e = 0; e < E / 2; ++e) {
-            k4[(u32)e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-            m4[(u32)e * NT + tid] = make_uint4(0u, 0u, 0u, 0u);
-        }
+        for (u32 e = 0; e < T / 2 / NT; ++e) k4[e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    };
+    auto clear_lo = [&]() { if (tid < T / 4) reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u); };
+    auto clear_hi = [&]() { if (tid < T / 4) reinterpret_cast<uint4*>(tmhi)[tid] = make_uint4(0u, 0u, 0u, 0u); };
+    auto clear_ovf = [&]() {
         unsigned long long e0 = EMPTY;   // (opaque, as `emptyv` below)
         asm volatile("" : "+v"(e0));
-        for (u32 i = tid; i < T2; i += NT) { ovf.key[i] = e0; ovf.mlo[i] = 0u; ovf.mhi[i] = 0u; }
+        if (tid < T2) { okey[tid] = e0; omlo[tid] = 0u; omhi[tid] = 0u; }
     };
-    for (u32 i = tid; i < (u32)KH_TAG_MAX_OPS; i += NT) { ginfo[i] = jb.ginfo[i]; dupc[i] = 0; }
-    for (u32 i = tid; i < nbins * 8u; i += NT) hstripe[i] = 0;
-    clear_tables();
-    const u32 nrec = have < cap2 ? have : cap2;
-    if (nrec > SKM_SPEC) {   // uniform, rare
-#pragma unroll
-        for (u32 j = 0; j < SKM_URPT; ++j) {
-            const u32 i = SKM_URPT * tid + j;
-            if (i >= SKM_SPEC && i < nrec) rr[j] = reg[i];
-        }
+    SKM_MARK("init");
+    if (tid < (u32)KH_TAG_MAX_OPS) { ginfo[tid] = jb.ginfo[tid]; dupc[tid] = 0; }
+    if (tid < SKM_HSTRIPE_WORDS) hstripe[tid] = 0;
+    clear_lo();
+    clear_hi();
+    clear_ovf();
+    u32 nj = 0;   // k-mers of this thread's record while it is alive
+    const u32 tg = (rr.w >> 21) & 63u;
+    if (tid < nrec) {
+        nj = rr.w >> 27;
+        stage[tid] = rr;
+        rmask[tid] = 1u << (tg & 31u);
     }
-    // ---- number the slot's k-mers: record i holds indices [roff[i], roff[i] + n_i)
-    u32 nj[SKM_URPT], mine = 0;
-#pragma unroll
-    for (u32 j = 0; j < SKM_URPT; ++j) {
-        nj[j] = SKM_URPT * tid + j < nrec ? rr[j].w >> 27 : 0u;
-        mine += nj[j];
-    }
-    const u32 incl = wave_scan_add(mine);
-    if (lane == KH_WAVE - 1) scratch[wid] = incl;
     SKM_STAMP(0);
     __syncthreads();
     SKM_STAMP(1);
-    u32 off = incl - mine, N = 0;
-    for (u32 q = 0; q < SKM_UNW; ++q) {
-        const u32 v = scratch[q];
-        off += q < wid ? v : 0u;
-        N += v;
-    }
-    if (tid == 0 && N > T) atomicMax(jb.ctl + 1, N);
-    if (N > (u32)SKM_UE * SKM_OWN) {   // uniform: a slot this full goes back to the host
-        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
-        N = 0;
-    }
-    if (N) {
-#pragma unroll
-        for (u32 j = 0; j < SKM_URPT; ++j) {
-            if (nj[j]) {
-                roff[SKM_URPT * tid + j] = (u16)off;
-                for (u32 c = (off + (u32)E - 1) / (u32)E; c <= (off + nj[j] - 1) / (u32)E; ++c) owner[c] = (u16)(SKM_URPT * tid + j);
-                off += nj[j];
+    SKM_MARK("dedup");
+    // ---- identical records meet: the first keeps its place, the others add their genome bit to its mask
+    {
+        u32 h = rr.x * 0x9E3779B1u ^ rr.y * 0x85EBCA77u ^ rr.z * 0xC2B2AE3Du ^ (rr.w & ~(63u << 21)) * 0x27D4EB2Fu;
+        h ^= h >> 15;
+        h *= 0x2C1B3C6Du;
+        u32 hp = h >> (32 - HBITS);
+        bool pend = nj != 0;
+        while (__builtin_amdgcn_ballot_w64(pend)) {
+            if (pend) {
+                const u32 old = atomicCAS(&dd[hp], 0u, tid + 1u);
+                if (old == 0u) {
+                    pend = false;   // the first record with this content
+                } else {
+                    const uint4 o = stage[old - 1u];
+                    // the same bases, the same number of k-mers, a genome of the same half of the mask
+                    if (o.x == rr.x && o.y == rr.y && o.z == rr.z && ((o.w ^ rr.w) & ~(31u << 21)) == 0u) {
+                        const u32 bit = 1u << (tg & 31u);
+                        const u32 was = atomicOr(&rmask[old - 1u], bit);
+                        if (was & bit) atomicAdd(&dupc[tg], nj);   // a second copy inside one genome: nj repeats
+                        nj = 0;
+                        pend = false;
+                    } else {
+                        hp = (hp + 1u) & (T - 1u);
+                    }
+                }
             }
         }
     }
-    __syncthreads();
+    SKM_MARK("dedup_end");
     SKM_STAMP(2);
+    __syncthreads();   // the staged records and the set of contents are dead: the table takes their place
+    clear_keys();
+    clear_lo();
+    // ---- number the chunks of the records that are left: chunks in the low half, k-mers in the high half of one scan
+    const u32 nch = (nj + (u32)E - 1u) / (u32)E;
+    const u32 packed = nch | (nj << 16);
+    const u32 incl = wave_scan_add(packed);
+    if (lane == KH_WAVE - 1) scratch[wid] = incl;
+    __syncthreads();
+    SKM_STAMP(3);
+    u32 C, N, cstart;
+    {
+        const u32 wtot = wave_scan_add(lane < NW ? scratch[lane] : 0u);   // lanes 0 .. NW-1: inclusive totals of the waves
+        const u32 tot = (u32)__builtin_amdgcn_readlane((int)wtot, (int)NW - 1);
+        const u32 before = wid ? (u32)__builtin_amdgcn_readlane((int)wtot, (int)wid - 1) : 0u;
+        C = tot & 0xffffu;
+        N = tot >> 16;
+        cstart = ((before + incl - packed) & 0xffffu);
+    }
+    SKM_MARK("after_scan");
+    if (tid == 0) {
+        if (N > T) atomicMax(jb.ctl + 1, N);
+        atomicAdd(jb.ctl + 3, N);   // k-mer instances that are expanded
+    }
+    if (C > G::MAXCH) {   // uniform: a slot this full goes back to the host
+        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+        C = 0;
+        N = 0;
+    }
+    if (C) {
+#pragma unroll
+        for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
+            if (cc < nch) owner[cstart + cc] = (u16)((tid << SKM_OB) | cc);
+    }
+    __syncthreads();
+    SKM_MARK("owner_done");
+    SKM_STAMP(4);
     const u32 R = (N + T - 1) / T;   // key subsets handled one after the other (1 unless the slot is overfull)
-    const u64 kmask = kh_mask(2 * k);
-    auto eval_mask = [&](u64 mask, u32 g) -> u32 {
+    // Chunks are taken by the first C threads of a ROTATED numbering of the waves: about half of a workgroup's waves
+    // have chunks, a wave stays on one SIMD, and waves 0, 4, 8 .. share a SIMD: without the rotation the SIMD of
+    // wave 0 carried three of nine busy waves of EVERY workgroup on the CU and set the pace of the kernel.
+    const u32 ctid = (((wid + ((blockIdx.x * 2654435761u) >> 16)) & (NW - 1u)) << 6) | lane;
+    // the 2k-bit mask and where the last base of a k-mer sits, as 32-bit halves (20 <= k <= 32: the low word is full)
+    const u32 kmh = (u32)(kh_mask(2 * k) >> 32);
+    const u32 fsh = 64u - 2u * (u32)k;          // right-aligns a reversed window
+    const u32 tsh = 2u * (u32)k - 2u;           // 38 .. 62
+    const u32 tsh_hi = tsh - 32u;               // 6 .. 30
+    unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
+    auto hist_add = [&](u32 bin) { atomicAdd(&hstripe[(bin << sshift) + (lane & smask)], 1u); };
+    // one distinct k-mer: popcount of its mask per group -> the group's bin; number of groups -> across bin
+    // (returns true when the k-mer sits in exactly one group: those are counted per wave)
+    auto eval_mask = [&](u64 mask) -> bool {
         u32 ng = 0;
-        while (true) {
+        do {
+            const u32 g = ginfo[__ffsll((unsigned long long)mask) - 1];
             const u32 g0 = g & 0xffu, gn = (g >> 8) & 0xffu, bin0 = g >> 16;
             const u64 gm = (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0;
             u32 c = (u32)__popcll(mask & gm);
             c = c < cs ? c : cs;
-            atomicAdd(&hstripe[(bin0 + c) * 8u + (lane & 7u)], 1u);
+            hist_add(bin0 + c);
             mask &= ~gm;
             ++ng;
-            if (!mask) break;
-            g = ginfo[__ffsll((unsigned long long)mask) - 1];
-        }
-        return ng < cs ? ng : cs;
+        } while (mask);
+        if (ng == 1u) return true;
+        hist_add(jb.abase + (ng < cs ? ng : cs));
+        return false;
     };
     for (u32 q = 0; q < R; ++q) {
-        if (q) { clear_tables(); __syncthreads(); }
+        if (q) { clear_keys(); clear_lo(); clear_hi(); clear_ovf(); __syncthreads(); }
         unsigned long long emptyv = EMPTY;   // (opaque: made here, or the compiler keeps the constant in two VGPRs across the loop and spills it)
         asm volatile("" : "+v"(emptyv));
-        for (u32 base = 0; base < N; base += NT * (u32)E) {
-            {
-                const u32 j0 = base + (u32)E * tid;
-                u64 kreg[E];
-                u32 tagp[(E + 3) / 4], slot_[E], act = 0;
+        // entries this thread created, per pass: four 16-bit fields (bit 15: set = valid, bit 14: second table)
+        u32 made[SKM_PASSES][E / 2];
 #pragma unroll
-                for (int w2 = 0; w2 < (E + 3) / 4; ++w2) tagp[w2] = 0;
-                if (j0 < N) {
-                    u32 ri = owner[j0 / (u32)E];
-                    u32 o = j0 - roff[ri];
-                    const uint4 r0 = reg[ri];
-#if KH_TUNE_SKM_PREFETCH
-                    uint4 q1 = ri + 1 < nrec ? reg[ri + 1] : make_uint4(0, 0, 0, 0);   // the record behind it, in flight
-#endif
-                    u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
-                    u32 cn = r0.w >> 27, ctag = (r0.w >> 21) & 63u;
+        for (u32 ps = 0; ps < SKM_PASSES; ++ps)
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        kreg[e] = EMPTY;
-                        slot_[e] = 0;
-                        if (j0 + (u32)e < N) {
-                            if (o == cn) {
-                                ++ri;
-#if KH_TUNE_SKM_PREFETCH
-                                uint4 r = q1;
-                                q1 = make_uint4(0, 0, 0, 0);
-                                if (!(r.w >> 27)) r = reg[ri < nrec ? ri : nrec - 1];   // past the preloaded one (a record holds n >= 1)
-#else
-                                const uint4 r = reg[ri < nrec ? ri : nrec - 1];   // an L2 hit: the records were read a moment ago
-#endif
-                                clo = ((u64)r.y << 32) | r.x;
-                                chi = ((u64)r.w << 32) | r.z;
-                                cn = r.w >> 27;
-                                ctag = (r.w >> 21) & 63u;
-                                o = 0;
-                            }
-                            const u32 sh = 2 * o;
-                            const u64 x = (sh ? (clo >> sh) | ((chi << 1) << (63 - sh)) : clo) & kmask;
-                            const u64 f = kh_revpairs64(x) >> (64 - 2 * k);
-                            const u64 rc = (~x) & kmask;
-                            const u64 can = f < rc ? f : rc;
-                            const u32 h = key_hash(can);
-                            kreg[e] = can;
-                            slot_[e] = h >> (32 - HBITS);
-                            tagp[e >> 2] |= ctag << (8 * (e & 3));
-                            if (R == 1 || (((h >> 4) & 0xffffu) * R) >> 16 == q) act |= 1u << e;
-                            ++o;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) { kreg[e] = EMPTY; slot_[e] = 0; }
-                }
-                auto tag = [&](int e) -> u32 { return (tagp[e >> 2] >> (8 * (e & 3))) & 63u; };
-                SKM_STAMP(3);
-                // ---- probe rounds, all of a thread's keys per round (one dependent LDS round trip per round)
-                u32 was[E];   // the half of the genome mask that holds this key's bit, as it was: bit set already = a repeat inside the genome
-#pragma unroll
-                for (int e = 0; e < E; ++e) was[e] = 0u;
-#define SKM_PROBE_ROUNDS(TBL, TMASK, ROUNDS)                                                                          \
-    for (u32 round = 0; round < (ROUNDS) && __builtin_amdgcn_ballot_w64(act != 0); ++round) {                        \
-        unsigned long long old[E];                                                                                    \
-        _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                 \
-            old[e] = (act & (1u << e)) ? atomicCAS(&(TBL).key[slot_[e]], emptyv, (unsigned long long)kreg[e]) : 0ull;  \
-        _Pragma("unroll") for (int e = 0; e < E; ++e) {                                                               \
-            if (act & (1u << e)) {                                                                                    \
-                if (old[e] == emptyv || old[e] == kreg[e]) {                                                           \
-                    was[e] = atomicOr(((tag(e) & 32u) ? (TBL).mhi : (TBL).mlo) + slot_[e],                            \
-                                      1u << (tag(e) & 31u));   /* looked at after the last round */                   \
-                    act &= ~(1u << e);                                                                                \
-                } else {                                                                                              \
-                    slot_[e] = (slot_[e] + 1u) & (TMASK);                                                             \
-                }                                                                                                     \
-            }                                                                                                         \
-        }                                                                                                             \
-    }
-                SKM_PROBE_ROUNDS(tbl, T - 1u, (u32)KH_TUNE_SKM_FULL_ROUNDS)
-                SKM_STAMP(9);
-#if KH_TUNE_SKM_OVF_SERIAL
-                // the few keys still homeless (~2 %): one per lane at a time, second table, then the main one again
-                while (__builtin_amdgcn_ballot_w64(act != 0)) {
-                    const bool have_one = act != 0;
-                    const u32 es = have_one ? (u32)__builtin_ctz(act) : 0u;
-                    u64 K = 0;
-                    u32 tg = 0;
-#pragma unroll
-                    for (int e = 0; e < E; ++e)
-                        if (es == (u32)e) { K = kreg[e]; tg = tag(e); }
-                    const u32 H = key_hash(K);
-                    // level 0: the rest of the key's KH_HASH_ROUNDS probes in the main table, 1: second table, 2: main table, unbounded
-                    u32 S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> 24, probes = 0, level = 1, tmask = T2 - 1u;
-                    if ((u32)KH_TUNE_SKM_FULL_ROUNDS < (u32)KH_HASH_ROUNDS) {
-                        S = ((H >> (32 - HBITS)) + (u32)KH_TUNE_SKM_FULL_ROUNDS) & (T - 1u);
-                        probes = (u32)KH_TUNE_SKM_FULL_ROUNDS; level = 0; tmask = T - 1u;
-                    }
-                    bool mine = have_one;
-                    while (__builtin_amdgcn_ballot_w64(mine)) {
-                        if (mine) {
-                            unsigned long long* kp = level == 1 ? ovf.key : tbl.key;
-                            const unsigned long long o2 = atomicCAS(&kp[S], emptyv, (unsigned long long)K);
-                            if (o2 == emptyv || o2 == K) {
-                                u32* mp = level == 1 ? ((tg & 32u) ? ovf.mhi : ovf.mlo) : ((tg & 32u) ? tbl.mhi : tbl.mlo);
-                                const u32 w = atomicOr(mp + S, 1u << (tg & 31u));
-                                if ((w >> (tg & 31u)) & 1u) atomicAdd(&dupc[tg], 1u);
-                                mine = false;
-                            } else {
-                                ++probes;
-                                if (level == 0 && probes >= (u32)KH_HASH_ROUNDS) {
-                                    level = 1; probes = 0; tmask = T2 - 1u;
-                                    S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> 24;
-                                } else if (level == 1 && probes >= T2) {
-                                    level = 2; probes = 0; tmask = T - 1u;
-                                    S = ((H >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
-                                } else if (level == 2 && probes >= T) {
-                                    atomicOr(jb.ctl, KH_ERR_CAPACITY);   // cannot happen: a round holds at most T keys
-                                    mine = false;
-                                } else {
-                                    S = (S + 1u) & tmask;
-                                }
-                            }
-                        }
-                    }
-                    if (have_one) act &= ~(1u << es);
-                }
-#endif
-                if (__builtin_amdgcn_ballot_w64(act != 0)) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) { const u32 h = key_hash(kreg[e]); slot_[e] = ((h ^ (h >> 15)) * 0x85EBCA77u) >> 24; }   // T2 = 256
-                    SKM_PROBE_ROUNDS(ovf, T2 - 1u, T2)
-                    if (__builtin_amdgcn_ballot_w64(act != 0)) {   // second table full of other keys: on in the main table
-#pragma unroll
-                        for (int e = 0; e < E; ++e) slot_[e] = ((key_hash(kreg[e]) >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
-                        SKM_PROBE_ROUNDS(tbl, T - 1u, T)
-                        if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
-                    }
-                }
-#undef SKM_PROBE_ROUNDS
-#pragma unroll
-                for (int e = 0; e < E; ++e)
-                    if ((was[e] >> (tag(e) & 31u)) & 1u) atomicAdd(&dupc[tag(e)], 1u);
-                SKM_STAMP(4);
-            }
-        }
-        __syncthreads();
-        SKM_STAMP(5);
-        // ---- every occupied entry is one distinct key of the slot: genome mask -> histogram bins
-        // (the thread number through an opaque copy: addresses formed from it are worked out here, not kept in
-        // registers across the insertion loop — where the compiler spilled them, 28 bytes of scratch per
-        // thread = 1.5 GB of HBM writes per step)
-        u32 tid_ro = tid;
-        asm volatile("" : "+v"(tid_ro));
-        u64 mk[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const u32 i = (u32)e * NT + tid_ro;
-            mk[e] = tbl.key[i] != EMPTY ? (((u64)tbl.mhi[i] << 32) | tbl.mlo[i]) : 0ull;
-        }
-        u32 gi[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) gi[e] = ginfo[mk[e] ? __ffsll((unsigned long long)mk[e]) - 1 : 0];
+            for (int e = 0; e < E / 2; ++e) made[ps][e] = 0u;
         u32 ones = 0;   // keys that sit in exactly one group
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (!mk[e]) continue;
-            const u32 ng = eval_mask(mk[e], gi[e]);
-            if (ng == 1u) ++ones;
-            else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
-        }
-        for (u32 i = tid_ro; i < T2; i += NT) {   // keys that moved to the second table (a few per slot)
-            if (ovf.key[i] != EMPTY) {
-                const u64 emask = ((u64)ovf.mhi[i] << 32) | ovf.mlo[i];
-                const u32 ng = eval_mask(emask, ginfo[__ffsll((unsigned long long)emask) - 1]);
-                if (ng == 1u) ++ones;
-                else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
+        for (u32 pass = 0; pass < SKM_PASSES; ++pass) {
+            if (pass * NT >= C) break;   // uniform
+            const u32 c = pass * NT + ctid;
+            u64 kreg[E];
+            u32 slot_[E], act = 0, bits = 0, half = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { kreg[e] = EMPTY; slot_[e] = 0; }
+            if (c < C) {
+                const u32 o = owner[c], ri = o >> SKM_OB, first = (o & ((1u << SKM_OB) - 1u)) * (u32)E;
+                const uint4 r0 = reg[ri];   // an L2 hit: the records were read a moment ago
+                bits = rmask[ri];
+                half = (r0.w >> 26) & 1u;
+                const u32 left = (r0.w >> 27) - first;
+                const u32 cnt = left < (u32)E ? left : (u32)E;
+                const u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
+                const u32 sh = 2u * first;   // 0, 8, .. 56
+                const u64 lo = sh ? (clo >> sh) | (chi << (64u - sh)) : clo, hi = chi >> sh;
+                const u32 xl = (u32)lo, xh = (u32)(lo >> 32) & kmh;   // the first k-mer, base j at bits 2j
+                const u64 fw = kh_revpairs64(((u64)xh << 32) | xl) >> fsh;
+                u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl, rh = ~xh & kmh;
+                const u32 t = (u32)((lo >> tsh) | (hi << (64u - tsh)));   // bits 2e: the last base of the chunk's k-mer e
+                const u32 tc = ~t;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (e) {   // roll both strands by one base
+                        fh = __builtin_amdgcn_alignbit(fh, fl, 30) & kmh;
+                        fl = (fl << 2) | ((t >> (2 * e)) & 3u);
+                        rl = __builtin_amdgcn_alignbit(rh, rl, 2);
+                        rh = (rh >> 2) | (((tc >> (2 * e)) & 3u) << tsh_hi);
+                    }
+                    const bool fwd = fh < rh || (fh == rh && fl < rl);
+                    const u32 cl = fwd ? fl : rl, ch = fwd ? fh : rh;
+                    const u32 h = key_hash2(cl, ch);
+                    kreg[e] = ((u64)ch << 32) | cl;
+                    slot_[e] = h >> (32 - HBITS);
+                    if (R != 1 && (u32)e < cnt && (((h >> 4) & 0xffffu) * R) >> 16 == q) act |= 1u << e;
+                }
+                if (R == 1) act = (1u << cnt) - 1u;
+            }
+            SKM_MARK("expanded");
+            if (!__builtin_amdgcn_ballot_w64(act != 0)) continue;   // a wave without a chunk
+            u32* const mp = half ? tmhi : tmlo;
+            // ---- probe rounds, all of a thread's keys per round (one dependent LDS round trip per round)
+            u32 was[E];   // the mask half as it was: bits of this record's genomes set already = repeats inside those genomes
+#pragma unroll
+            for (int e = 0; e < E; ++e) was[e] = 0u;
+            u32 mk = 0;   // keys whose compare-and-swap created the entry
+            for (u32 round = 0; round < (u32)KH_TUNE_SKM_FULL_ROUNDS && __builtin_amdgcn_ballot_w64(act != 0); ++round) {
+                unsigned long long old[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    old[e] = (act & (1u << e)) ? atomicCAS(&tkey[slot_[e]], emptyv, (unsigned long long)kreg[e]) : 0ull;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (act & (1u << e)) {
+                        const bool fresh = old[e] == emptyv;
+                        if (fresh || old[e] == kreg[e]) {
+                            was[e] = atomicOr(mp + slot_[e], bits);   // looked at after the last round
+                            act &= ~(1u << e);
+                            if (fresh) mk |= 1u << e;
+                        } else {
+                            slot_[e] = (slot_[e] + 1u) & (T - 1u);
+                        }
+                    }
+                }
+            }
+            SKM_MARK("rounds_done");
+            SKM_STAMP(9);
+            u32 f16[E];   // where each key's entry is, if this thread created it
+#pragma unroll
+            for (int e = 0; e < E; ++e) f16[e] = (mk >> e) & 1u ? (0x8000u | slot_[e]) : 0u;
+            // the few keys still homeless (~2 %): one per lane at a time, second table, then the main one again
+            while (__builtin_amdgcn_ballot_w64(act != 0)) {
+                const bool have_one = act != 0;
+                const u32 es = have_one ? (u32)__builtin_ctz(act) : 0u;
+                u64 K = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (es == (u32)e) K = kreg[e];
+                const u32 H = key_hash2((u32)K, (u32)(K >> 32));
+                // level 0: the rest of the key's KH_HASH_ROUNDS probes in the main table, 1: second table, 2: main table, unbounded
+                u32 S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> (32 - HBITS + 5), probes = 0, level = 1, tmask = T2 - 1u;   // T2 = T / 32
+                if ((u32)KH_TUNE_SKM_FULL_ROUNDS < (u32)KH_HASH_ROUNDS) {
+                    S = ((H >> (32 - HBITS)) + (u32)KH_TUNE_SKM_FULL_ROUNDS) & (T - 1u);
+                    probes = (u32)KH_TUNE_SKM_FULL_ROUNDS; level = 0; tmask = T - 1u;
+                }
+                bool mine = have_one;
+                u32 where = 0;
+                while (__builtin_amdgcn_ballot_w64(mine)) {
+                    if (mine) {
+                        unsigned long long* kp = level == 1 ? okey : tkey;
+                        const unsigned long long o2 = atomicCAS(&kp[S], emptyv, (unsigned long long)K);
+                        if (o2 == emptyv || o2 == K) {
+                            u32* mp2 = level == 1 ? (half ? omhi : omlo) : mp;
+                            u32 d = atomicOr(mp2 + S, bits) & bits;
+                            while (d) { atomicAdd(&dupc[half * 32u + (u32)__builtin_ctz(d)], 1u); d &= d - 1u; }
+                            if (o2 == emptyv) where = 0x8000u | (level == 1 ? 0x4000u : 0u) | S;
+                            mine = false;
+                        } else {
+                            ++probes;
+                            if (level == 0 && probes >= (u32)KH_HASH_ROUNDS) {
+                                level = 1; probes = 0; tmask = T2 - 1u;
+                                S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> (32 - HBITS + 5);
+                            } else if (level == 1 && probes >= T2) {
+                                level = 2; probes = 0; tmask = T - 1u;
+                                S = ((H >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
+                            } else if (level == 2 && probes >= T) {
+                                atomicOr(jb.ctl, KH_ERR_CAPACITY);   // cannot happen: a round holds at most T keys
+                                mine = false;
+                            } else {
+                                S = (S + 1u) & tmask;
+                            }
+                        }
+                    }
+                }
+                if (have_one) {
+                    act &= ~(1u << es);
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if (es == (u32)e) f16[e] = where;
+                }
+            }
+            SKM_MARK("serial_done");
+#pragma unroll
+            for (int e = 0; e < E / 2; ++e) made[pass][e] = f16[2 * e] | (f16[2 * e + 1] << 16);
+            {   // repeats inside a genome: the bit was set before this instance came
+                u32 d = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) d |= was[e] & bits;
+                if (d) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        u32 de = was[e] & bits;
+                        while (de) { atomicAdd(&dupc[half * 32u + (u32)__builtin_ctz(de)], 1u); de &= de - 1u; }
+                    }
+                }
             }
         }
-        ones = wave_scan_add(ones);
-        if (lane == KH_WAVE - 1 && ones) atomicAdd(&hstripe[(jb.abase + 1u) * 8u], ones);
-        SKM_STAMP(6);
+        SKM_MARK("insert_done");
+        SKM_STAMP(5);
         __syncthreads();
+        SKM_STAMP(6);
+        // ---- all masks are final: every thread turns the entries it created into histogram bins
+#pragma unroll
+        for (u32 pass = 0; pass < SKM_PASSES; ++pass) {
+            u32 any = 0;
+#pragma unroll
+            for (int e = 0; e < E / 2; ++e) any |= made[pass][e];
+            if (!__builtin_amdgcn_ballot_w64(any != 0)) continue;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const u32 f = (made[pass][e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                if (f & 0x8000u) {
+                    const u32 at = f & 0x3fffu;
+                    const bool second = f & 0x4000u;
+                    const u64 m = ((u64)(second ? omhi : tmhi)[at] << 32) | (second ? omlo : tmlo)[at];
+                    if (eval_mask(m)) ++ones;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(ones != 0)) {
+            ones = wave_scan_add(ones);
+            if (lane == KH_WAVE - 1) atomicAdd(&hstripe[(jb.abase + 1u) << sshift], ones);
+        }
+        SKM_MARK("readout_done");
         SKM_STAMP(7);
+        if (q + 1 < R) __syncthreads();
     }
-    unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
+    __syncthreads();
     for (u32 i = tid; i < nbins; i += NT) {
         u32 v = 0;
-#pragma unroll
-        for (u32 j = 0; j < 8; ++j) v += hstripe[i * 8u + j];
+        for (u32 j = 0; j <= smask; ++j) v += hstripe[(i << sshift) + j];
         if (v) atomicAdd(&rep[i], (unsigned long long)v);
     }
     if (tid < (u32)KH_TAG_MAX_OPS && dupc[tid]) atomicAdd(&jb.dup[tid], (unsigned long long)dupc[tid]);
@@ -704,7 +770,12 @@ void kh_launch_skm_regroup(const KhSkmJob& job, hipStream_t st) {
     hipLaunchKernelGGL(k_skm_regroup, dim3(job.nb1), dim3(SKM_RG_NT), lds, st, job);
 }
 void kh_launch_skm_union(const KhSkmJob& job, u32 cs, hipStream_t st) {
-    const size_t lds = kh_skm_union_lds_bytes(job.nbins);
-    skm_allow_lds(k_skm_union, lds);
-    hipLaunchKernelGGL(k_skm_union, dim3(job.nslots), dim3(SKM_UNT), lds, st, job, cs);
+    const size_t lds = kh_skm_union_lds_bytes(job.table);
+    if (job.table == 2048) {
+        skm_allow_lds(k_skm_union<512, 2048>, lds);
+        hipLaunchKernelGGL((k_skm_union<512, 2048>), dim3(job.nslots), dim3(512), lds, st, job, cs);
+    } else {
+        skm_allow_lds(k_skm_union<1024, 4096>, lds);
+        hipLaunchKernelGGL((k_skm_union<1024, 4096>), dim3(job.nslots), dim3(1024), lds, st, job, cs);
+    }
 }
