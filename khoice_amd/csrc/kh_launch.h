@@ -163,7 +163,8 @@ size_t kh_skm_union_lds_bytes(u32 table);
 u32 kh_skm_union_max_cap2(u32 table);   // records of a slot the union with that table takes
 void kh_launch_skm_scatter(const KhSkmJob& job, u32 ntiles, hipStream_t st);
 void kh_launch_skm_regroup(const KhSkmJob& job, hipStream_t st);
-void kh_launch_skm_union(const KhSkmJob& job, u32 cs, hipStream_t st);
+void kh_launch_skm_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st);   // persistent: grid workgroups walk the slots
+u32 kh_skm_union_per_cu(u32 table);   // workgroups of the union that fit a CU
 // the same three steps for two-word keys (kh_skm2.hip): 32-byte records (two uint4 per record in reg1 / reg2)
 constexpr int KH_SKM2_MAX_K = 63;         // k = 64: the all-ones low key word is a k-mer (A^32 T^32)
 constexpr u32 KH_SKM2_MAX_COARSE = 512;

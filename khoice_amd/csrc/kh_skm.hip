@@ -51,7 +51,7 @@ void kh_debug_set_stamps_skm(u64* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_skm_
 #define SKM_MARK(name) do {} while (0)
 #endif
 #ifndef KH_TUNE_SKM_FULL_ROUNDS
-#define KH_TUNE_SKM_FULL_ROUNDS KH_TUNE_HASH_ROUNDS   // probe rounds made by all keys of a thread together; the rest one key per lane
+#define KH_TUNE_SKM_FULL_ROUNDS 4   // probe rounds made by all keys of a thread together; the rest one key per lane (1 / 2 / 3 / 4 / 5 / 8 rounds: union 16.3 / 3.33 / 1.59 / 1.51 / 1.52 / 1.55 ms)
 #endif
 #ifndef KH_TUNE_SKM_SCATTER_PREFETCH
 #define KH_TUNE_SKM_SCATTER_PREFETCH 0   // 1: the next sub-tile's bases wait in registers while this one is processed (0.656 ms against 0.624: three workgroups per CU hide the load as well, with fewer registers)
@@ -371,24 +371,41 @@ __global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm_regroup(const KhSkmJob jb)
 #endif
 constexpr u32 SKM_UE = KH_TUNE_SKM_UE;                // k-mers per chunk (2 or 4)
 constexpr u32 SKM_OB = SKM_UE == 2 ? 4 : 3;           // bits of a chunk's number inside its record (n <= 31)
-constexpr u32 SKM_PASSES = SKM_UE == 2 ? 4 : 2;       // chunks of a slot: at most SKM_PASSES per thread
+constexpr u32 SKM_PASSES = SKM_UE == 2 ? 3 : 2;       // chunks of a slot: at most SKM_PASSES per thread
 constexpr u32 SKM_HSTRIPE_WORDS = 288;                // histogram copies in LDS: 4 / 2 / 1 per bin for <= 72 / 144 / 255 bins
 template <u32 NT, u32 T> struct SkmUnionGeo {
     static constexpr u32 T2 = T / 32;                 // second table
     static constexpr u32 MAXREC = NT;                 // records of a slot (cap2 <= this): one per thread
     static constexpr u32 MAXCH = SKM_PASSES * NT;     // chunks of a slot (after the merge of identical records)
     static constexpr u32 HBITS = T == 4096 ? 12 : (T == 2048 ? 11 : 10);
-    static constexpr size_t LDS = (size_t)T * 16 + (size_t)T2 * 16 + 256 + 128 + 256 + (size_t)SKM_HSTRIPE_WORDS * 4 +
+    static constexpr size_t LDS = (size_t)T * 16 + (size_t)T2 * 16 + 1024 + 128 + 256 + (size_t)SKM_HSTRIPE_WORDS * 4 +
                                   (size_t)MAXCH * 2 + (size_t)MAXREC * 4;
-    static_assert(MAXREC * 16 <= T * 8, "records are staged in the key plane");
+    static_assert(MAXREC * 16 <= T * 4, "records are staged in the first half of the key plane");
     static_assert(T2 <= NT && T / 4 <= NT, "clears are one store per thread");
 };
 u32 kh_skm_union_threads(u32 table) { return table == 2048 ? 512u : 1024u; }
 u32 kh_skm_union_max_cap2(u32 table) { return kh_skm_union_threads(table); }
+u32 kh_skm_union_per_cu(u32 table) { return table == 2048 ? 3u : 2u; }
 size_t kh_skm_union_lds_bytes(u32 table) { return table == 2048 ? SkmUnionGeo<512, 2048>::LDS : SkmUnionGeo<1024, 4096>::LDS; }
 
 __device__ __forceinline__ u32 key_hash2(u32 lo, u32 hi) { return (lo ^ hi) * 0x9E3779B1u; }
 
+#ifdef KH_STAMPS
+#define SKM_USTAMP(idx)                                                                    \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (threadIdx.x == 0 && g_skm_stamps) g_skm_stamps[(u64)slot * 16 + (idx)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+#else
+#define SKM_USTAMP(idx) do {} while (0)
+#endif
+
+// PERSISTENT: the grid is two workgroups per CU (what the LDS allows); a workgroup walks slots blockIdx.x,
+// blockIdx.x + gridDim.x, ...  While it works on one slot the record of the next one is already on its way to the
+// thread's registers and the count of the one after to a scalar register: a workgroup that started with "load the
+// count, then load the records" spent 2.5 of its 6 microseconds waiting for memory with nothing else to do.  The
+// histogram bins and the repeat counters stay in LDS over all slots of the workgroup and are written once.
 template <u32 NT, u32 T>
 __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
@@ -404,342 +421,385 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
     unsigned long long* okey = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T2 * 8;
     u32* omlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
     u32* omhi = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
-    u32* ginfo = reinterpret_cast<u32*>(p);                                p += 256;
+    uint4* gtab = reinterpret_cast<uint4*>(p);                             p += 1024;   // per operand: its group's mask (two halves), first bin << sshift
     u32* scratch = reinterpret_cast<u32*>(p);                              p += 128;
     u32* dupc = reinterpret_cast<u32*>(p);                                 p += 256;
     u32* hstripe = reinterpret_cast<u32*>(p);                              p += (size_t)SKM_HSTRIPE_WORDS * 4;
-    u16* owner = reinterpret_cast<u16*>(p);                                p += (size_t)G::MAXCH * 2;   // chunk -> record << 3 | chunk of the record
+    u16* owner = reinterpret_cast<u16*>(p);                                p += (size_t)G::MAXCH * 2;   // chunk -> record << SKM_OB | chunk of the record
     u32* rmask = reinterpret_cast<u32*>(p);                                // [MAXREC] genomes (of one half of the mask) that hold the record
-    // while identical records are merged the table is not in use yet: the records are staged in its key plane, the
-    // set of their contents (record number + 1, 0: empty) is its low mask plane
+    // While identical records are merged the table is not in use yet (and its KEY plane is not read any more once a
+    // slot's insertions are over): the records are staged in the first half of the key plane, the set of their
+    // contents (record number + 1, 0: empty) is the second half.
     uint4* stage = reinterpret_cast<uint4*>(tkey);
-    u32* dd = tmlo;
-    const u32 tid = threadIdx.x, lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const u32 nbins = jb.nbins;
+    u32* dd = reinterpret_cast<u32*>(tkey) + T;
+    const u32 tid0 = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    u32 tid = tid0, lane = lane_id();
+    const u32 nbins = jb.nbins, cap2 = jb.cap2, nslots = jb.nslots, stride = gridDim.x;
     const int k = jb.k;
-    const u32 slot = blockIdx.x;
     const u32 sshift = nbins <= 72u ? 2u : (nbins <= 144u ? 1u : 0u), smask = (1u << sshift) - 1u;
-    const uint4* __restrict__ reg = jb.reg2 + (u64)slot * jb.cap2;
-    // ---- the slot's records, one per thread; their number comes by a scalar load first: nothing is fetched that
-    // is not a record
-    u32 nrec = jb.cur2[slot];
-    nrec = nrec < jb.cap2 ? nrec : jb.cap2;
-    nrec = nrec < G::MAXREC ? nrec : G::MAXREC;
-    const uint4 rr = tid < nrec ? reg[tid] : make_uint4(0, 0, 0, 0);
     auto clear_keys = [&]() {
         uint4* k4 = reinterpret_cast<uint4*>(tkey);
 #pragma unroll
         for (u32 e = 0; e < T / 2 / NT; ++e) k4[e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
     };
-    auto clear_lo = [&]() { if (tid < T / 4) reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u); };
-    auto clear_hi = [&]() { if (tid < T / 4) reinterpret_cast<uint4*>(tmhi)[tid] = make_uint4(0u, 0u, 0u, 0u); };
-    auto clear_ovf = [&]() {
+    auto clear_masks = [&]() {
+        if (tid < T / 4) {
+            reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint4*>(tmhi)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        }
         unsigned long long e0 = EMPTY;   // (opaque, as `emptyv` below)
         asm volatile("" : "+v"(e0));
         if (tid < T2) { okey[tid] = e0; omlo[tid] = 0u; omhi[tid] = 0u; }
     };
+    // the record counts were written by the regroup kernel and do not change here: read through the constant address
+    // space, i.e. by SCALAR loads (inside the slot loop the compiler cannot prove that for a plain global pointer)
+    typedef const u32 __attribute__((address_space(4))) * ConstU32;
+    const ConstU32 counts = (ConstU32)(unsigned long long)jb.cur2;
+    auto count_of = [&](u32 sl) -> u32 {
+        u32 n = sl < nslots ? counts[sl] : 0u;
+        n = n < cap2 ? n : cap2;
+        return n < G::MAXREC ? n : G::MAXREC;
+    };
     SKM_MARK("init");
-    if (tid < (u32)KH_TAG_MAX_OPS) { ginfo[tid] = jb.ginfo[tid]; dupc[tid] = 0; }
+    if (tid < (u32)KH_TAG_MAX_OPS) {
+        const u32 g = jb.ginfo[tid], g0 = g & 0xffu, gn = (g >> 8) & 0xffu;
+        const u64 gm = gn ? (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0 : 0ull;
+        gtab[tid] = make_uint4((u32)gm, (u32)(gm >> 32), (g >> 16) << sshift, 0u);
+        dupc[tid] = 0;
+    }
     if (tid < SKM_HSTRIPE_WORDS) hstripe[tid] = 0;
-    clear_lo();
-    clear_hi();
-    clear_ovf();
-    u32 nj = 0;   // k-mers of this thread's record while it is alive
-    const u32 tg = (rr.w >> 21) & 63u;
-    if (tid < nrec) {
-        nj = rr.w >> 27;
-        stage[tid] = rr;
-        rmask[tid] = 1u << (tg & 31u);
-    }
-    SKM_STAMP(0);
-    __syncthreads();
-    SKM_STAMP(1);
-    SKM_MARK("dedup");
-    // ---- identical records meet: the first keeps its place, the others add their genome bit to its mask
-    {
-        u32 h = rr.x * 0x9E3779B1u ^ rr.y * 0x85EBCA77u ^ rr.z * 0xC2B2AE3Du ^ (rr.w & ~(63u << 21)) * 0x27D4EB2Fu;
-        h ^= h >> 15;
-        h *= 0x2C1B3C6Du;
-        u32 hp = h >> (32 - HBITS);
-        bool pend = nj != 0;
-        while (__builtin_amdgcn_ballot_w64(pend)) {
-            if (pend) {
-                const u32 old = atomicCAS(&dd[hp], 0u, tid + 1u);
-                if (old == 0u) {
-                    pend = false;   // the first record with this content
-                } else {
-                    const uint4 o = stage[old - 1u];
-                    // the same bases, the same number of k-mers, a genome of the same half of the mask
-                    if (o.x == rr.x && o.y == rr.y && o.z == rr.z && ((o.w ^ rr.w) & ~(31u << 21)) == 0u) {
-                        const u32 bit = 1u << (tg & 31u);
-                        const u32 was = atomicOr(&rmask[old - 1u], bit);
-                        if (was & bit) atomicAdd(&dupc[tg], nj);   // a second copy inside one genome: nj repeats
-                        nj = 0;
-                        pend = false;
-                    } else {
-                        hp = (hp + 1u) & (T - 1u);
-                    }
-                }
-            }
-        }
-    }
-    SKM_MARK("dedup_end");
-    SKM_STAMP(2);
-    __syncthreads();   // the staged records and the set of contents are dead: the table takes their place
-    clear_keys();
-    clear_lo();
-    // ---- number the chunks of the records that are left: chunks in the low half, k-mers in the high half of one scan
-    const u32 nch = (nj + (u32)E - 1u) / (u32)E;
-    const u32 packed = nch | (nj << 16);
-    const u32 incl = wave_scan_add(packed);
-    if (lane == KH_WAVE - 1) scratch[wid] = incl;
-    __syncthreads();
-    SKM_STAMP(3);
-    u32 C, N, cstart;
-    {
-        const u32 wtot = wave_scan_add(lane < NW ? scratch[lane] : 0u);   // lanes 0 .. NW-1: inclusive totals of the waves
-        const u32 tot = (u32)__builtin_amdgcn_readlane((int)wtot, (int)NW - 1);
-        const u32 before = wid ? (u32)__builtin_amdgcn_readlane((int)wtot, (int)wid - 1) : 0u;
-        C = tot & 0xffffu;
-        N = tot >> 16;
-        cstart = ((before + incl - packed) & 0xffffu);
-    }
-    SKM_MARK("after_scan");
-    if (tid == 0) {
-        if (N > T) atomicMax(jb.ctl + 1, N);
-        atomicAdd(jb.ctl + 3, N);   // k-mer instances that are expanded
-    }
-    if (C > G::MAXCH) {   // uniform: a slot this full goes back to the host
-        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
-        C = 0;
-        N = 0;
-    }
-    if (C) {
-#pragma unroll
-        for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
-            if (cc < nch) owner[cstart + cc] = (u16)((tid << SKM_OB) | cc);
-    }
-    __syncthreads();
-    SKM_MARK("owner_done");
-    SKM_STAMP(4);
-    const u32 R = (N + T - 1) / T;   // key subsets handled one after the other (1 unless the slot is overfull)
-    // Chunks are taken by the first C threads of a ROTATED numbering of the waves: about half of a workgroup's waves
-    // have chunks, a wave stays on one SIMD, and waves 0, 4, 8 .. share a SIMD: without the rotation the SIMD of
-    // wave 0 carried three of nine busy waves of EVERY workgroup on the CU and set the pace of the kernel.
-    const u32 ctid = (((wid + ((blockIdx.x * 2654435761u) >> 16)) & (NW - 1u)) << 6) | lane;
+    if (tid == 0) scratch[0] = 0;
     // the 2k-bit mask and where the last base of a k-mer sits, as 32-bit halves (20 <= k <= 32: the low word is full)
     const u32 kmh = (u32)(kh_mask(2 * k) >> 32);
     const u32 fsh = 64u - 2u * (u32)k;          // right-aligns a reversed window
     const u32 tsh = 2u * (u32)k - 2u;           // 38 .. 62
     const u32 tsh_hi = tsh - 32u;               // 6 .. 30
-    unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
-    auto hist_add = [&](u32 bin) { atomicAdd(&hstripe[(bin << sshift) + (lane & smask)], 1u); };
     // one distinct k-mer: popcount of its mask per group -> the group's bin; number of groups -> across bin
-    // (returns true when the k-mer sits in exactly one group: those are counted per wave)
-    auto eval_mask = [&](u64 mask) -> bool {
+    // (returns true when the k-mer sits in exactly one group — nearly all do: those are counted per wave)
+    auto eval_mask = [&](u32 mlo, u32 mhi) -> bool {
+        const u32 lsel = lane & smask;
         u32 ng = 0;
         do {
-            const u32 g = ginfo[__ffsll((unsigned long long)mask) - 1];
-            const u32 g0 = g & 0xffu, gn = (g >> 8) & 0xffu, bin0 = g >> 16;
-            const u64 gm = (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0;
-            u32 c = (u32)__popcll(mask & gm);
+            const u32 first = mlo ? (u32)__builtin_ctz(mlo) : 32u + (u32)__builtin_ctz(mhi);
+            const uint4 g = gtab[first];
+            u32 c = (u32)__popc(mlo & g.x) + (u32)__popc(mhi & g.y);
             c = c < cs ? c : cs;
-            hist_add(bin0 + c);
-            mask &= ~gm;
+            atomicAdd(&hstripe[g.z + (c << sshift) + lsel], 1u);
+            const u32 keep_hi = mlo ? ~0u : mhi - 1u;   // (the lowest bit goes in any case: a tag outside every group cannot hang the loop)
+            mlo &= ~g.x & (mlo - 1u);
+            mhi &= ~g.y & keep_hi;
             ++ng;
-        } while (mask);
+        } while (mlo | mhi);
         if (ng == 1u) return true;
-        hist_add(jb.abase + (ng < cs ? ng : cs));
+        atomicAdd(&hstripe[((jb.abase + (ng < cs ? ng : cs)) << sshift) + lsel], 1u);
         return false;
     };
-    for (u32 q = 0; q < R; ++q) {
-        if (q) { clear_keys(); clear_lo(); clear_hi(); clear_ovf(); __syncthreads(); }
-        unsigned long long emptyv = EMPTY;   // (opaque: made here, or the compiler keeps the constant in two VGPRs across the loop and spills it)
-        asm volatile("" : "+v"(emptyv));
-        // entries this thread created, per pass: four 16-bit fields (bit 15: set = valid, bit 14: second table)
-        u32 made[SKM_PASSES][E / 2];
-#pragma unroll
-        for (u32 ps = 0; ps < SKM_PASSES; ++ps)
-#pragma unroll
-            for (int e = 0; e < E / 2; ++e) made[ps][e] = 0u;
-        u32 ones = 0;   // keys that sit in exactly one group
-#pragma unroll
-        for (u32 pass = 0; pass < SKM_PASSES; ++pass) {
-            if (pass * NT >= C) break;   // uniform
-            const u32 c = pass * NT + ctid;
-            u64 kreg[E];
-            u32 slot_[E], act = 0, bits = 0, half = 0;
-#pragma unroll
-            for (int e = 0; e < E; ++e) { kreg[e] = EMPTY; slot_[e] = 0; }
-            if (c < C) {
-                const u32 o = owner[c], ri = o >> SKM_OB, first = (o & ((1u << SKM_OB) - 1u)) * (u32)E;
-                const uint4 r0 = reg[ri];   // an L2 hit: the records were read a moment ago
-                bits = rmask[ri];
-                half = (r0.w >> 26) & 1u;
-                const u32 left = (r0.w >> 27) - first;
-                const u32 cnt = left < (u32)E ? left : (u32)E;
-                const u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
-                const u32 sh = 2u * first;   // 0, 8, .. 56
-                const u64 lo = sh ? (clo >> sh) | (chi << (64u - sh)) : clo, hi = chi >> sh;
-                const u32 xl = (u32)lo, xh = (u32)(lo >> 32) & kmh;   // the first k-mer, base j at bits 2j
-                const u64 fw = kh_revpairs64(((u64)xh << 32) | xl) >> fsh;
-                u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl, rh = ~xh & kmh;
-                const u32 t = (u32)((lo >> tsh) | (hi << (64u - tsh)));   // bits 2e: the last base of the chunk's k-mer e
-                const u32 tc = ~t;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    if (e) {   // roll both strands by one base
-                        fh = __builtin_amdgcn_alignbit(fh, fl, 30) & kmh;
-                        fl = (fl << 2) | ((t >> (2 * e)) & 3u);
-                        rl = __builtin_amdgcn_alignbit(rh, rl, 2);
-                        rh = (rh >> 2) | (((tc >> (2 * e)) & 3u) << tsh_hi);
-                    }
-                    const bool fwd = fh < rh || (fh == rh && fl < rl);
-                    const u32 cl = fwd ? fl : rl, ch = fwd ? fh : rh;
-                    const u32 h = key_hash2(cl, ch);
-                    kreg[e] = ((u64)ch << 32) | cl;
-                    slot_[e] = h >> (32 - HBITS);
-                    if (R != 1 && (u32)e < cnt && (((h >> 4) & 0xffffu) * R) >> 16 == q) act |= 1u << e;
-                }
-                if (R == 1) act = (1u << cnt) - 1u;
-            }
-            SKM_MARK("expanded");
-            if (!__builtin_amdgcn_ballot_w64(act != 0)) continue;   // a wave without a chunk
-            u32* const mp = half ? tmhi : tmlo;
-            // ---- probe rounds, all of a thread's keys per round (one dependent LDS round trip per round)
-            u32 was[E];   // the mask half as it was: bits of this record's genomes set already = repeats inside those genomes
-#pragma unroll
-            for (int e = 0; e < E; ++e) was[e] = 0u;
-            u32 mk = 0;   // keys whose compare-and-swap created the entry
-            for (u32 round = 0; round < (u32)KH_TUNE_SKM_FULL_ROUNDS && __builtin_amdgcn_ballot_w64(act != 0); ++round) {
-                unsigned long long old[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e)
-                    old[e] = (act & (1u << e)) ? atomicCAS(&tkey[slot_[e]], emptyv, (unsigned long long)kreg[e]) : 0ull;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    if (act & (1u << e)) {
-                        const bool fresh = old[e] == emptyv;
-                        if (fresh || old[e] == kreg[e]) {
-                            was[e] = atomicOr(mp + slot_[e], bits);   // looked at after the last round
-                            act &= ~(1u << e);
-                            if (fresh) mk |= 1u << e;
+    u32 st_full = 0, st_exp = 0;   // fullest slot seen, k-mer instances expanded (uniform)
+    // ---- pipeline prologue: this slot's record, the next slot's count
+    u32 slot = blockIdx.x;
+    u32 nrec = count_of(slot);
+    u32 nrec_next = count_of(slot + stride);
+    uint4 rr = tid < nrec ? (jb.reg2 + (u64)slot * cap2)[tid] : make_uint4(0, 0, 0, 0);
+    for (; slot < nslots; slot += stride) {
+        // (the thread number through an opaque copy, per slot: the many LDS addresses formed from it are worked out
+        // where they are used instead of being kept in registers — and spilled — across the whole loop)
+        tid = tid0;
+        asm volatile("" : "+v"(tid));
+        lane = tid & (KH_WAVE - 1u);
+        const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2;
+        const u32 nrec_after = count_of(slot + 2u * stride);   // (a scalar load: two slots ahead)
+        // ---- stage this slot's records, one per thread
+        u32 nj = 0;   // k-mers of this thread's record while it is alive
+        const u32 tg = (rr.w >> 21) & 63u;
+        const u32 rx = rr.x, ry = rr.y, rz = rr.z, rw = rr.w;   // (this slot's record; `rr` is loaded again below)
+        {
+            u32 z = 0;   // (opaque: a zero kept in four registers across the loop was spilled)
+            asm volatile("" : "+v"(z));
+            if (tid < T / 4) reinterpret_cast<uint4*>(dd)[tid] = make_uint4(z, z, z, z);
+        }
+        if (tid < nrec) {
+            nj = rr.w >> 27;
+            stage[tid] = rr;
+            rmask[tid] = 1u << (tg & 31u);
+        }
+        SKM_USTAMP(0);
+        __syncthreads();
+        SKM_USTAMP(1);
+        SKM_MARK("dedup");
+        // ---- identical records meet: the first keeps its place, the others add their genome bit to its mask.  A
+        // record that stays takes its chunks from a counter (chunks in the low half, k-mers in the high half) and
+        // enters them into the chunk table at once: no block scan, no phase of its own.
+        if (__builtin_amdgcn_ballot_w64(nj != 0)) {   // (waves without records go straight to the barrier)
+            u32 h = rx * 0x9E3779B1u ^ ry * 0x85EBCA77u ^ rz * 0xC2B2AE3Du ^ (rw & ~(63u << 21)) * 0x27D4EB2Fu;
+            h ^= h >> 15;
+            h *= 0x2C1B3C6Du;
+            u32 hp = h >> (32 - HBITS);
+            const u32 nch = (nj + (u32)E - 1u) / (u32)E;
+            bool pend = nj != 0, won = false;
+            while (__builtin_amdgcn_ballot_w64(pend)) {
+                if (pend) {
+                    const u32 old = atomicCAS(&dd[hp], 0u, tid + 1u);
+                    if (old == 0u) {   // the first record with this content
+                        won = true;
+                        pend = false;
+                    } else {
+                        const uint4 o = stage[old - 1u];
+                        // the same bases, the same number of k-mers, a genome of the same half of the mask
+                        if (o.x == rx && o.y == ry && o.z == rz && ((o.w ^ rw) & ~(31u << 21)) == 0u) {
+                            const u32 bit = 1u << (tg & 31u);
+                            const u32 was = atomicOr(&rmask[old - 1u], bit);
+                            if (was & bit) atomicAdd(&dupc[tg], nj);   // a second copy inside one genome: nj repeats
+                            pend = false;
                         } else {
-                            slot_[e] = (slot_[e] + 1u) & (T - 1u);
+                            hp = (hp + 1u) & (T - 1u);
                         }
                     }
                 }
             }
-            SKM_MARK("rounds_done");
-            SKM_STAMP(9);
-            u32 f16[E];   // where each key's entry is, if this thread created it
+            // the wave's records take consecutive chunks in lane order (their loads in the expansion stay
+            // coalesced); the wave's share comes from one returning LDS atomic
+            const u32 mine = won ? (nch | (nj << 16)) : 0u;
+            const u32 incl = wave_scan_add(mine);
+            u32 wbase = 0;
+            if (lane == KH_WAVE - 1 && incl) wbase = atomicAdd(&scratch[0], incl);
+            wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
+            if (won) {
+                const u32 cstart = (wbase + incl - mine) & 0xffffu;
+                if (cstart + nch <= G::MAXCH) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) f16[e] = (mk >> e) & 1u ? (0x8000u | slot_[e]) : 0u;
-            // the few keys still homeless (~2 %): one per lane at a time, second table, then the main one again
-            while (__builtin_amdgcn_ballot_w64(act != 0)) {
-                const bool have_one = act != 0;
-                const u32 es = have_one ? (u32)__builtin_ctz(act) : 0u;
-                u64 K = 0;
-#pragma unroll
-                for (int e = 0; e < E; ++e)
-                    if (es == (u32)e) K = kreg[e];
-                const u32 H = key_hash2((u32)K, (u32)(K >> 32));
-                // level 0: the rest of the key's KH_HASH_ROUNDS probes in the main table, 1: second table, 2: main table, unbounded
-                u32 S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> (32 - HBITS + 5), probes = 0, level = 1, tmask = T2 - 1u;   // T2 = T / 32
-                if ((u32)KH_TUNE_SKM_FULL_ROUNDS < (u32)KH_HASH_ROUNDS) {
-                    S = ((H >> (32 - HBITS)) + (u32)KH_TUNE_SKM_FULL_ROUNDS) & (T - 1u);
-                    probes = (u32)KH_TUNE_SKM_FULL_ROUNDS; level = 0; tmask = T - 1u;
+                    for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
+                        if (cc < nch) owner[cstart + cc] = (u16)((tid << SKM_OB) | cc);
                 }
-                bool mine = have_one;
-                u32 where = 0;
-                while (__builtin_amdgcn_ballot_w64(mine)) {
-                    if (mine) {
-                        unsigned long long* kp = level == 1 ? okey : tkey;
-                        const unsigned long long o2 = atomicCAS(&kp[S], emptyv, (unsigned long long)K);
-                        if (o2 == emptyv || o2 == K) {
-                            u32* mp2 = level == 1 ? (half ? omhi : omlo) : mp;
-                            u32 d = atomicOr(mp2 + S, bits) & bits;
-                            while (d) { atomicAdd(&dupc[half * 32u + (u32)__builtin_ctz(d)], 1u); d &= d - 1u; }
-                            if (o2 == emptyv) where = 0x8000u | (level == 1 ? 0x4000u : 0u) | S;
-                            mine = false;
-                        } else {
-                            ++probes;
-                            if (level == 0 && probes >= (u32)KH_HASH_ROUNDS) {
-                                level = 1; probes = 0; tmask = T2 - 1u;
-                                S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> (32 - HBITS + 5);
-                            } else if (level == 1 && probes >= T2) {
-                                level = 2; probes = 0; tmask = T - 1u;
-                                S = ((H >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
-                            } else if (level == 2 && probes >= T) {
-                                atomicOr(jb.ctl, KH_ERR_CAPACITY);   // cannot happen: a round holds at most T keys
-                                mine = false;
+            }
+        }
+        SKM_MARK("dedup_end");
+        SKM_USTAMP(2);
+        __syncthreads();   // the staged records and the set of contents are dead, the previous slot's masks are read: the table is made
+        // ---- the next slot's record sets out now, into the registers this slot's record has just left: it has the
+        // expansion and the read-out to arrive
+        rr = tid < nrec_next ? (jb.reg2 + (u64)(slot + stride) * cap2)[tid] : make_uint4(0, 0, 0, 0);
+        clear_keys();
+        clear_masks();
+        u32 C = scratch[0] & 0xffffu, N = scratch[0] >> 16;
+        SKM_USTAMP(3);
+        SKM_MARK("after_scan");
+        st_full = N > st_full ? N : st_full;
+        st_exp += N;
+        if (C > G::MAXCH) {   // uniform: a slot this full goes back to the host
+            if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+            C = 0;
+            N = 0;
+        }
+#if defined(KH_ABLATE) && KH_ABLATE == 1
+        C = 0; N = 0;   // timing study: nothing is expanded
+#endif
+        __syncthreads();
+        if (tid == 0) scratch[0] = 0;   // (everybody has read it; it is added to again behind the next slot's first barrier)
+        SKM_MARK("owner_done");
+        SKM_USTAMP(4);
+        const u32 R = (N + T - 1) / T;   // key subsets handled one after the other (1 unless the slot is overfull)
+        // Chunks are taken by the first C threads of a ROTATED numbering of the waves (a slot with fewer chunks than
+        // threads keeps different SIMDs busy from slot to slot).
+        const u32 ctid = (((wid + ((slot * 2654435761u) >> 16)) & (NW - 1u)) << 6) | lane;
+        for (u32 q = 0; q < R; ++q) {
+            if (q) { clear_keys(); clear_masks(); __syncthreads(); }
+            unsigned long long emptyv = EMPTY;   // (opaque: made here, or the compiler keeps the constant in two VGPRs across the loop and spills it)
+            asm volatile("" : "+v"(emptyv));
+            // entries this thread created, per pass: 16-bit fields (bit 15: set = valid, bit 14: second table)
+            u32 made[SKM_PASSES][E / 2];
+#pragma unroll
+            for (u32 ps = 0; ps < SKM_PASSES; ++ps)
+#pragma unroll
+                for (int e = 0; e < E / 2; ++e) made[ps][e] = 0u;
+            u32 ones = 0;   // keys that sit in exactly one group
+#pragma unroll
+            for (u32 pass = 0; pass < SKM_PASSES; ++pass) {
+                if (pass * NT >= C) break;   // uniform
+                const u32 c = pass * NT + ctid;
+                u64 kreg[E];
+                u32 slot_[E], act = 0, bits = 0, half = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) { kreg[e] = EMPTY; slot_[e] = 0; }
+                if (c < C) {
+                    const u32 o = owner[c], ri = o >> SKM_OB, first = (o & ((1u << SKM_OB) - 1u)) * (u32)E;
+                    const uint4 r0 = reg[ri];   // an L2 hit: the records were read a moment ago
+                    bits = rmask[ri];
+                    half = (r0.w >> 26) & 1u;
+                    const u32 left = (r0.w >> 27) - first;
+                    const u32 cnt = left < (u32)E ? left : (u32)E;
+                    const u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
+                    const u32 sh = 2u * first;   // 0, 2E, .. <= 60
+                    const u64 lo = sh ? (clo >> sh) | (chi << (64u - sh)) : clo, hi = chi >> sh;
+                    const u32 xl = (u32)lo, xh = (u32)(lo >> 32) & kmh;   // the first k-mer, base j at bits 2j
+                    const u64 fw = kh_revpairs64(((u64)xh << 32) | xl) >> fsh;
+                    u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl, rh = ~xh & kmh;
+                    const u32 t = (u32)((lo >> tsh) | (hi << (64u - tsh)));   // bits 2e: the last base of the chunk's k-mer e
+                    const u32 tc = ~t;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if (e) {   // roll both strands by one base
+                            fh = __builtin_amdgcn_alignbit(fh, fl, 30) & kmh;
+                            fl = (fl << 2) | ((t >> (2 * e)) & 3u);
+                            rl = __builtin_amdgcn_alignbit(rh, rl, 2);
+                            rh = (rh >> 2) | (((tc >> (2 * e)) & 3u) << tsh_hi);
+                        }
+                        const bool fwd = fh < rh || (fh == rh && fl < rl);
+                        const u32 cl = fwd ? fl : rl, ch = fwd ? fh : rh;
+                        const u32 h = key_hash2(cl, ch);
+                        kreg[e] = ((u64)ch << 32) | cl;
+                        slot_[e] = h >> (32 - HBITS);
+                        if (R != 1 && (u32)e < cnt && (((h >> 4) & 0xffffu) * R) >> 16 == q) act |= 1u << e;
+                    }
+                    if (R == 1) act = (1u << cnt) - 1u;
+                }
+#if defined(KH_ABLATE) && KH_ABLATE == 2
+                if (kreg[0] != 0x1234567ull) act = 0;   // timing study: expanded, not inserted
+#endif
+                SKM_MARK("expanded");
+                if (!__builtin_amdgcn_ballot_w64(act != 0)) continue;   // a wave without a chunk
+                u32* const mp = half ? tmhi : tmlo;
+                // ---- probe rounds, all of a thread's keys per round (one dependent LDS round trip per round)
+                u32 was[E];   // the mask half as it was: bits of this record's genomes set already = repeats inside those genomes
+#pragma unroll
+                for (int e = 0; e < E; ++e) was[e] = 0u;
+                u32 mk = 0;   // keys whose compare-and-swap created the entry
+                for (u32 round = 0; round < (u32)KH_TUNE_SKM_FULL_ROUNDS && __builtin_amdgcn_ballot_w64(act != 0); ++round) {
+                    unsigned long long old[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        old[e] = (act & (1u << e)) ? atomicCAS(&tkey[slot_[e]], emptyv, (unsigned long long)kreg[e]) : 0ull;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if (act & (1u << e)) {
+                            const bool fresh = old[e] == emptyv;
+                            if (fresh || old[e] == kreg[e]) {
+                                was[e] = atomicOr(mp + slot_[e], bits);   // looked at after the last round
+                                act &= ~(1u << e);
+                                if (fresh) mk |= 1u << e;
                             } else {
-                                S = (S + 1u) & tmask;
+                                slot_[e] = (slot_[e] + 1u) & (T - 1u);
                             }
                         }
                     }
                 }
-                if (have_one) {
-                    act &= ~(1u << es);
+                SKM_USTAMP(9);
+                SKM_MARK("rounds_done");
+                u32 f16[E];   // where each key's entry is, if this thread created it
+#pragma unroll
+                for (int e = 0; e < E; ++e) f16[e] = (mk >> e) & 1u ? (0x8000u | slot_[e]) : 0u;
+                // the few keys still homeless: one per lane at a time, second table, then the main one again
+                while (__builtin_amdgcn_ballot_w64(act != 0)) {
+                    const bool have_one = act != 0;
+                    const u32 es = have_one ? (u32)__builtin_ctz(act) : 0u;
+                    u64 K = 0;
 #pragma unroll
                     for (int e = 0; e < E; ++e)
-                        if (es == (u32)e) f16[e] = where;
+                        if (es == (u32)e) K = kreg[e];
+                    const u32 H = key_hash2((u32)K, (u32)(K >> 32));
+                    // level 1: second table, 2: main table, unbounded
+                    u32 S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> (32 - HBITS + 5), probes = 0, level = 1, tmask = T2 - 1u;   // T2 = T / 32
+                    bool mine = have_one;
+                    u32 where = 0;
+                    while (__builtin_amdgcn_ballot_w64(mine)) {
+                        if (mine) {
+                            unsigned long long* kp = level == 1 ? okey : tkey;
+                            const unsigned long long o2 = atomicCAS(&kp[S], emptyv, (unsigned long long)K);
+                            if (o2 == emptyv || o2 == K) {
+                                u32* mp2 = level == 1 ? (half ? omhi : omlo) : mp;
+                                u32 d = atomicOr(mp2 + S, bits) & bits;
+                                while (d) { atomicAdd(&dupc[half * 32u + (u32)__builtin_ctz(d)], 1u); d &= d - 1u; }
+                                if (o2 == emptyv) where = 0x8000u | (level == 1 ? 0x4000u : 0u) | S;
+                                mine = false;
+                            } else {
+                                ++probes;
+                                if (level == 1 && probes >= 8u) {   // a crowded second table: on in the main one
+                                    level = 2; probes = 0; tmask = T - 1u;
+                                    S = ((H >> (32 - HBITS)) + (u32)KH_TUNE_SKM_FULL_ROUNDS) & (T - 1u);
+                                } else if (level == 2 && probes >= T) {
+                                    atomicOr(jb.ctl, KH_ERR_CAPACITY);   // cannot happen: a round holds at most T keys
+                                    mine = false;
+                                } else {
+                                    S = (S + 1u) & tmask;
+                                }
+                            }
+                        }
+                    }
+                    if (have_one) {
+                        act &= ~(1u << es);
+#pragma unroll
+                        for (int e = 0; e < E; ++e)
+                            if (es == (u32)e) f16[e] = where;
+                    }
                 }
-            }
-            SKM_MARK("serial_done");
+                SKM_MARK("serial_done");
 #pragma unroll
-            for (int e = 0; e < E / 2; ++e) made[pass][e] = f16[2 * e] | (f16[2 * e + 1] << 16);
-            {   // repeats inside a genome: the bit was set before this instance came
-                u32 d = 0;
+                for (int e = 0; e < E / 2; ++e) made[pass][e] = f16[2 * e] | (f16[2 * e + 1] << 16);
+                {   // repeats inside a genome: the bit was set before this instance came
+                    u32 d = 0;
 #pragma unroll
-                for (int e = 0; e < E; ++e) d |= was[e] & bits;
-                if (d) {
+                    for (int e = 0; e < E; ++e) d |= was[e] & bits;
+                    if (d) {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        u32 de = was[e] & bits;
-                        while (de) { atomicAdd(&dupc[half * 32u + (u32)__builtin_ctz(de)], 1u); de &= de - 1u; }
+                        for (int e = 0; e < E; ++e) {
+                            u32 de = was[e] & bits;
+                            while (de) { atomicAdd(&dupc[half * 32u + (u32)__builtin_ctz(de)], 1u); de &= de - 1u; }
+                        }
                     }
                 }
             }
-        }
-        SKM_MARK("insert_done");
-        SKM_STAMP(5);
-        __syncthreads();
-        SKM_STAMP(6);
-        // ---- all masks are final: every thread turns the entries it created into histogram bins
+            SKM_MARK("insert_done");
+            SKM_USTAMP(5);
+            __syncthreads();
+            SKM_USTAMP(6);
+            // ---- all masks are final: every thread turns the entries it created into histogram bins
 #pragma unroll
-        for (u32 pass = 0; pass < SKM_PASSES; ++pass) {
-            u32 any = 0;
+            for (u32 pass = 0; pass < SKM_PASSES; ++pass) {
+                u32 any = 0;
 #pragma unroll
-            for (int e = 0; e < E / 2; ++e) any |= made[pass][e];
-            if (!__builtin_amdgcn_ballot_w64(any != 0)) continue;
+                for (int e = 0; e < E / 2; ++e) any |= made[pass][e];
+#if defined(KH_ABLATE) && KH_ABLATE == 3
+                if (any != 0x7654321u) any = 0;   // timing study: no read-out
+#endif
+                if (!__builtin_amdgcn_ballot_w64(any != 0)) continue;
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const u32 f = (made[pass][e >> 1] >> (16 * (e & 1))) & 0xffffu;
-                if (f & 0x8000u) {
-                    const u32 at = f & 0x3fffu;
-                    const bool second = f & 0x4000u;
-                    const u64 m = ((u64)(second ? omhi : tmhi)[at] << 32) | (second ? omlo : tmlo)[at];
-                    if (eval_mask(m)) ++ones;
+                for (int e = 0; e < E; ++e) {
+                    const u32 f = (made[pass][e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                    if (f & 0x8000u) {
+                        const u32 at = f & 0x3fffu;
+                        const bool second = f & 0x4000u;
+                        if (eval_mask((second ? omlo : tmlo)[at], (second ? omhi : tmhi)[at])) ++ones;
+                    }
                 }
             }
+            if (__builtin_amdgcn_ballot_w64(ones != 0)) {
+                ones = wave_scan_add(ones);
+                if (lane == KH_WAVE - 1) atomicAdd(&hstripe[(jb.abase + 1u) << sshift], ones);
+            }
+            SKM_MARK("readout_done");
+            SKM_USTAMP(7);
+            if (q + 1 < R) __syncthreads();
         }
-        if (__builtin_amdgcn_ballot_w64(ones != 0)) {
-            ones = wave_scan_add(ones);
-            if (lane == KH_WAVE - 1) atomicAdd(&hstripe[(jb.abase + 1u) << sshift], ones);
-        }
-        SKM_MARK("readout_done");
-        SKM_STAMP(7);
-        if (q + 1 < R) __syncthreads();
+        SKM_USTAMP(8);
+        // ---- on to the next slot: its record has arrived in the meantime.  No barrier here: what the next slot writes
+        // before its first barrier (staged records, the set of contents: the KEY plane; this thread's record mask)
+        // is read by nobody in the read-out.
+        nrec = nrec_next;
+        nrec_next = nrec_after;
     }
     __syncthreads();
+    tid = tid0;
+    lane = tid & (KH_WAVE - 1u);
+    unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
     for (u32 i = tid; i < nbins; i += NT) {
         u32 v = 0;
         for (u32 j = 0; j <= smask; ++j) v += hstripe[(i << sshift) + j];
         if (v) atomicAdd(&rep[i], (unsigned long long)v);
     }
     if (tid < (u32)KH_TAG_MAX_OPS && dupc[tid]) atomicAdd(&jb.dup[tid], (unsigned long long)dupc[tid]);
-    SKM_STAMP(8);
+    if (tid == 0) {
+        if (st_full > T) atomicMax(jb.ctl + 1, st_full);
+        atomicAdd(jb.ctl + 3, st_exp);   // k-mer instances that were expanded
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -769,13 +829,13 @@ void kh_launch_skm_regroup(const KhSkmJob& job, hipStream_t st) {
     skm_allow_lds(k_skm_regroup, lds);
     hipLaunchKernelGGL(k_skm_regroup, dim3(job.nb1), dim3(SKM_RG_NT), lds, st, job);
 }
-void kh_launch_skm_union(const KhSkmJob& job, u32 cs, hipStream_t st) {
+void kh_launch_skm_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st) {
     const size_t lds = kh_skm_union_lds_bytes(job.table);
     if (job.table == 2048) {
         skm_allow_lds(k_skm_union<512, 2048>, lds);
-        hipLaunchKernelGGL((k_skm_union<512, 2048>), dim3(job.nslots), dim3(512), lds, st, job, cs);
+        hipLaunchKernelGGL((k_skm_union<512, 2048>), dim3(grid), dim3(512), lds, st, job, cs);
     } else {
         skm_allow_lds(k_skm_union<1024, 4096>, lds);
-        hipLaunchKernelGGL((k_skm_union<1024, 4096>), dim3(job.nslots), dim3(1024), lds, st, job, cs);
+        hipLaunchKernelGGL((k_skm_union<1024, 4096>), dim3(grid), dim3(1024), lds, st, job, cs);
     }
 }
