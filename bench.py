@@ -77,13 +77,14 @@ def kernel_algorithmic_bytes(name, st, k, nseq_bases):
         total = st["setop_in"] * kb + st["setop_out"] * (kb + 4)
     elif name == "union_tagged":
         total = st["setop_in"] * kb                  # reads every genome set once; writes histograms only
-    # super-k-mer form (khoice_amd/csrc/kh_skm.hip): what each kernel has to move, R = 16-byte records
+    # super-k-mer form (khoice_amd/csrc/kh_skm.hip, kh_skm2.hip): what each kernel has to move; a record is 16
+    # bytes with one-word keys (k <= 32), 32 bytes with two-word keys
     elif name == "skm_scatter":
-        total = steps_bases + st.get("skm_records", 0) * 16     # every base in, every record out
+        total = steps_bases + st.get("skm_records", 0) * (16 * w)     # every base in, every record out
     elif name == "skm_regroup":
-        total = st.get("skm_records", 0) * 32                    # every record in and out
+        total = st.get("skm_records", 0) * (32 * w)                    # every record in and out
     elif name == "skm_union":
-        total = st.get("skm_records", 0) * 16                    # every record in; histograms out
+        total = st.get("skm_records", 0) * (16 * w)                    # every record in; histograms out
     else:
         total = 0
     return total / launches

@@ -2038,6 +2038,15 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
     // emits its across-group set (counter = groups of the batch holding the k-mer) and one
     // counter-summing union of those sets gives step 7/8.  Anything the fused form cannot take
     // (a group of more than 64 genomes, a slot overflow) falls through to the general path below.
+    // A fast form that is abandoned part-way (a later batch or wave overflows) has already counted its earlier
+    // batches: the statistics of an attempt are kept only when the attempt succeeds.
+    const Stats stat_at_entry = c->stat;
+    auto forget_attempt = [&]() {
+        const u64 retries = c->stat.retries, order_fallbacks = c->stat.order_fallbacks;
+        c->stat = stat_at_entry;
+        c->stat.retries = retries;
+        c->stat.order_fallbacks = order_fallbacks;
+    };
     if (!group_sets && !getenv("KHOICE_NO_FUSED")) {
         u64 fbudget = 4ull << 30;
         size_t free_b = 0, total_b = 0;
@@ -2078,14 +2087,17 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
                 KHCHK(exp1_skm(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, within_hist, across_hist,
                                hist_len, distinct_per_seq, &done));
                 if (done) return KH_OK;
+                forget_attempt();
             }
             KHCHK(exp1_fused(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, within_hist, across_hist,
                              hist_len, distinct_per_seq, across_set, &done, waves_for(all_bases), 1.0, &scale));
             if (done) return KH_OK;
+            forget_attempt();
             if (scale > 1.0 && scale < 16.0) {   // one more try with finer slots before the general path
                 KHCHK(exp1_fused(c, nseq, seqs, lens, on_device, group_of, ngroups, k, cs, within_hist, across_hist,
                                  hist_len, distinct_per_seq, across_set, &done, waves_for(all_bases), scale, nullptr));
                 if (done) return KH_OK;
+                forget_attempt();
             }
         } else if (applicable) {
             const bool want_across = across_hist || across_set;
@@ -2124,6 +2136,7 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
                     if (distinct_per_seq) memcpy(distinct_per_seq, dtmp.data(), 8 * (size_t)nseq);
                     return KH_OK;
                 }
+                forget_attempt();
             }
             std::vector<kh_set*> asets;
             auto drop = [&]() { for (auto* s : asets) kh_set_free(s); asets.clear(); };
@@ -2165,6 +2178,7 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
                 return r;
             }
             drop();
+            forget_attempt();
         }
     }
     std::vector<kh_set*> gsets(nseq, nullptr), unions(ngroups, nullptr), usets(ngroups, nullptr);

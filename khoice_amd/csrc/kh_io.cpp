@@ -500,12 +500,15 @@ extern "C" int kh_dump_sorted(kh_ctx* c, const kh_set* s, const char* path) {
 // the array read 0
 extern "C" int kh_write_histogram_text(const char* path, const uint64_t* hist, uint32_t hist_len, uint32_t cmax) {
     if (!path || !hist || cmax < 1) return kh_fail(KH_E_ARG, "kh_write_histogram_text: bad argument");
+    // (the same limit as kh_histogram_file: the text of a three-byte counter's histogram is the longest this writes;
+    // an unbounded cmax would be a bad_alloc thrown through this extern "C" frame)
+    if (cmax > 0xffffffu) return kh_fail(KH_E_ARG, "kh_write_histogram_text: %u histogram lines requested (limit 16777215)", cmax);
     AtomicFile f;
     int r;
     if ((r = f.open(path)) != KH_OK) return r;
     // 65535 lines per file and six files per k: formatted by hand into one buffer (fprintf cost ~3 ms a file)
     std::vector<char> buf;
-    buf.reserve((size_t)cmax * 14 + 64);
+    try { buf.reserve((size_t)cmax * 14 + 64); } catch (const std::exception&) { return kh_fail(KH_E_NOMEM, "histogram text of %u lines", cmax); }
     char tmp[24];
     auto put = [&](unsigned long long v) {
         int m = 0;

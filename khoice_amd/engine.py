@@ -359,8 +359,8 @@ class Engine:
         return KmerSet(self, out.value)
 
     def ingest_fasta(self, paths: Sequence[str], threads: int = 0) -> DeviceTexts:
-        """(gz) FASTA files -> cleaned texts in HBM: parallel inflate into pinned memory on `threads`
-        host threads, FASTA cleaning on the device, file by file as they complete."""
+        """(gz) FASTA files -> cleaned texts in HBM: parallel inflate into (plain, not page-locked) host buffers on
+        `threads` host threads, FASTA cleaning on the device, file by file as they complete."""
         n = len(paths)
         arr = (C.c_char_p * n)(*[p.encode() for p in paths])
         out = C.c_void_p()

@@ -14,6 +14,9 @@ Sources executed:
   * workflow/rules/exp_type_2.smk:404-438  body of rule within_group_analysis_exp_type2
   * workflow/rules/exp_type_2.smk:521-554  body of rule across_group_analysis_exp_type2
   * src/merge_lists.py                     get_canonical_kmer, process_read_into_kmers
+  * src/merge_lists.py:53-73 composed      kmer_multiset.json: Counter of get_canonical_kmer(w) over
+                                           process_read_into_kmers(s, k) — the multiset of canonical k-mers
+                                           of an ACGT string by the reference's own two functions
   * src/merge_lists.py main()              feature-level confusion matrix + accuracy values
                                            (merge_lists.json; its text-dump inputs are written
                                            by OUR oracle, the three output files by the reference)
@@ -127,6 +130,58 @@ def gen_canonical(ml, rng):
         s = "".join(rng.choice("ACGT") for _ in range(L))
         out["windows"].append([s, k, ml.process_read_into_kmers(s, k)])
     return out
+
+
+def gen_kmer_multiset(ml, rng):
+    """The multiset of canonical k-mers of ACGT strings by the reference's own functions only:
+    collections.Counter(ml.get_canonical_kmer(w) for w in ml.process_read_into_kmers(s, k)).
+    Small cases carry the whole multiset, large ones its size, its total and the sha256 of its sorted
+    "KMER<TAB>count<LF>" text (the text `kmc_tools transform dump -s` would print for an unsaturated database)."""
+    import collections
+    import hashlib
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+    def dna(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+
+    def make(kind, k, n):
+        if kind == "random":
+            return dna(n)
+        if kind == "repeat":              # a unit repeated: counters above 1 (above 255 for the long ones)
+            unit = dna(rng.choice([1, 2, 3, 5, 8, 13]))
+            return (unit * (n // len(unit) + 1))[:n]
+        if kind == "palindromes":         # even k: reverse-complement palindromes between random stretches
+            out = ""
+            while len(out) < n:
+                half = dna(k // 2)
+                out += dna(rng.randrange(0, 7)) + half + "".join(comp[c] for c in reversed(half))
+            return out[:max(n, k)]
+        if kind == "both_strands":        # a stretch followed by its reverse complement: every k-mer meets its partner
+            half = dna(n // 2)
+            return half + "".join(comp[c] for c in reversed(half))
+        if kind == "duplicated":          # a segment copied inside the string
+            s = dna(n)
+            a = rng.randrange(0, max(1, n // 2))
+            return s + s[a:a + n // 3]
+        raise ValueError(kind)
+
+    cases = []
+    for k in (7, 15, 21, 31, 32, 33, 41, 63):
+        shapes = [("random", 0), ("random", k - 1), ("random", k), ("random", k + 1), ("random", 100), ("random", 1000),
+                  ("random", 5000), ("repeat", 400), ("repeat", 3000), ("both_strands", 600), ("duplicated", 900)]
+        if k % 2 == 0:
+            shapes += [("palindromes", 300)]
+        for kind, n in shapes:
+            s = make(kind, k, n)
+            cnt = collections.Counter(ml.get_canonical_kmer(w) for w in ml.process_read_into_kmers(s, k))
+            items = sorted(cnt.items())
+            text = "".join(f"{km}\t{c}\n" for km, c in items)
+            case = {"k": k, "kind": kind, "seq": s, "distinct": len(items), "total": sum(cnt.values()),
+                    "max_count": max(cnt.values()) if cnt else 0, "sha256": hashlib.sha256(text.encode()).hexdigest()}
+            if len(text) <= 4000:
+                case["multiset"] = items
+            cases.append(case)
+    return {"cases": cases}
 
 
 def gen_csv(s1, rng):
@@ -324,6 +379,7 @@ def main():
         "complex_ops.json": gen_complex_ops(),
         "merge_lists.json": gen_merge_lists(ml, random.Random(0x6D65726765)),
         "exp2_csv.json": gen_csv2(s2, random.Random(0x74797065)),
+        "kmer_multiset.json": gen_kmer_multiset(ml, random.Random(0x6D756C7469)),
     }
     for name, obj in out.items():
         with open(os.path.join(HERE, name), "w") as fh:

@@ -90,3 +90,36 @@ def test_read_fasta_host(lib, tmp_path):
     assert E.Engine.read_fasta(eng, str(gz)) == want
     with pytest.raises(E.KhoiceError):
         E.Engine.read_fasta(eng, str(tmp_path / "missing.fa"))
+
+
+def test_read_fasta_host_gives_the_oracles_records(lib, tmp_path):
+    """The host FASTA reader against the oracle's independent one (oracle/kmer_oracle.py fasta_records, SURVEY
+    App. A.1) — no GPU needed: CRLF line ends, a header at the end of the file, empty records, sequence before
+    the first header, '>' inside a line, a header line straddling a 4 KB boundary, random structure bytes.  What
+    has to agree is what the device will count: the non-empty runs of sequence, record by record."""
+    import random
+    from oracle import kmer_oracle as O
+    rng = random.Random(11)
+    cases = {
+        "crlf": ">r1\r\nACGT\r\nGGNN\r\n>r2\r\nTT\r\n",
+        "header_at_eof": ">r1\nACGT\n>r2",
+        "empty_records": ">a\n>b\n>c\nACGT\n>d\n>e\nGGCC\n>f\n",
+        "sequence_first": "ACGTAC\nGT\n>r1\nTTTT\n",
+        "gt_inside_line": ">r1\nAC>GT\nA>\n>r2\n>>\nAC\n",
+        "header_over_4k": ">r\n" + "A" * 4090 + "\n>" + "h" * 5000 + "\n" + "C" * 100 + "\n",
+        "blank_lines": "\n\n>r1\n\nACGT\n\n\nTTGA\n\n>r2\n\n",
+        "empty": "",
+    }
+    for i in range(20):
+        n = rng.choice([1, 17, 4095, 4096, 4097, 30_000])
+        cases[f"fuzz{i}"] = "".join(rng.choice("ACGTN>\n\n" if i % 2 else "ACGTacgtRY>\n") for _ in range(n))
+    eng = object.__new__(E.Engine)
+    eng._lib = lib
+    for name, text in cases.items():
+        for crlf in (False, True):
+            data = (text.replace("\n", "\r\n") if crlf and "\r" not in text else text).encode()
+            p = tmp_path / f"{name}_{int(crlf)}.fa"
+            p.write_bytes(data)
+            got = E.Engine.read_fasta(eng, str(p)).decode("latin-1")
+            want = [r for r in O.fasta_records(data) if r]
+            assert [r for r in got.split("\n") if r] == want, name

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import kmer_oracle as O
-from tests.util import db_to_arrays, random_dna, set_to_db
+from tests.util import check_multiset_case, db_to_arrays, random_dna, set_to_db
 
 pytestmark = pytest.mark.gpu
 
@@ -45,6 +45,27 @@ def messy_fasta(rng, n_records, rec_len, with_n=True, lower=True):
 
 def clean(fasta: bytes) -> bytes:
     return "\n".join(O.fasta_records(fasta)).encode()
+
+
+def test_build_matches_reference_multisets(eng, golden):
+    """K1 through the C ABI against reference-run output: tests/golden/kmer_multiset.json holds, for ACGT strings,
+    collections.Counter(get_canonical_kmer(w) for w in process_read_into_kmers(s, k)) computed by the reference's
+    own src/merge_lists.py:53-73 (repeats, both strands, even-k palindromes, k = 7 .. 63)."""
+    cases = golden("kmer_multiset.json")["cases"]
+    for k in sorted({c["k"] for c in cases}):
+        mine = [c for c in cases if c["k"] == k]
+        for cs in (0x7fffffff, 255):   # counters unsaturated, then KMC's default ceiling
+            sets = eng.build_batch([c["seq"].encode() for c in mine], k, cs=cs)
+            for case, st in zip(mine, sets):
+                keys, counts = st.download_sorted()
+                check_multiset_case(case, keys, counts, cs)
+    # the fused experiment-type-1 path on the same strings: one genome per group -> the group's histogram is the
+    # histogram of a set, the distinct count is the multiset's size
+    for k in (21, 31, 41, 63):
+        mine = [c for c in cases if c["k"] == k]
+        res = eng.exp1_run([c["seq"].encode() for c in mine], list(range(len(mine))), k, cs=5000, hist_len=16)
+        assert [int(x) for x in res["distinct_per_seq"]] == [c["distinct"] for c in mine]
+        assert [int(x) for x in res["within_hist"][:, 1]] == [c["distinct"] for c in mine]
 
 
 @pytest.mark.parametrize("k", [1, 3, 7, 15, 21, 31, 32, 33, 41, 63, 64])

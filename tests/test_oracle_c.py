@@ -7,7 +7,7 @@ import pytest
 
 from oracle import c_oracle as CO
 from oracle import kmer_oracle as O
-from tests.util import db_to_arrays, random_dna
+from tests.util import check_multiset_case, db_to_arrays, random_dna
 
 
 def same(db_c, db_py, k):
@@ -75,3 +75,12 @@ def test_exp1_matches_python():
         assert [int(x) for x in res["within_hist"][g]] == O.histogram(u, 5000)
     across = O.union_sum([O.set_counts(u, 1) for u in unions], 5000)
     assert [int(x) for x in res["across_hist"]] == O.histogram(across, 5000)
+
+
+def test_kmer_multisets_match_reference_through_c(golden):
+    """The C restatement against the reference-run multisets (tests/golden/kmer_multiset.json)."""
+    for case in golden("kmer_multiset.json")["cases"]:
+        keys, counts = CO.count(case["seq"].encode(), case["k"], cs=0x7fffffff).arrays()
+        check_multiset_case(case, keys, counts, 0x7fffffff)
+        keys, counts = CO.count(case["seq"].encode(), case["k"]).arrays()   # KMC's default ceiling of 255
+        check_multiset_case(case, keys, counts, 255)

@@ -2,6 +2,7 @@
 reference's src/merge_lists.py:53-73; counting semantics against hand-worked cases
 (KMC itself is unavailable: those are 'parity unpinned', see oracle/kmer_oracle.py)."""
 from oracle import kmer_oracle as O
+from tests.util import check_multiset_case, db_to_arrays
 
 
 def test_canonical_matches_reference(golden):
@@ -65,3 +66,15 @@ def test_parse_complex_ops_reference_grammar():
     assert inputs["set2"].endswith("b.transformed")
     one = "INPUT:\nset1 = p\nOUTPUT:\nq = (set1 )\nOUTPUT_PARAMS:\n-cs5000\n"
     assert O.parse_complex_ops(one)[2] == ["set1"]
+
+
+def test_kmer_multisets_match_reference(golden):
+    """K1's counting on ACGT input, pinned by reference-run output: for every case of kmer_multiset.json the
+    oracle's database of the string equals collections.Counter(get_canonical_kmer(w) for w in
+    process_read_into_kmers(s, k)) (src/merge_lists.py:53-73), counters unsaturated."""
+    cases = golden("kmer_multiset.json")["cases"]
+    assert len(cases) >= 80
+    for case in cases:
+        db = O.count_records([case["seq"]], case["k"], cs=1 << 30)
+        keys, counts = db_to_arrays(db, case["k"])
+        check_multiset_case(case, keys, counts, 1 << 30)

@@ -34,3 +34,30 @@ def set_to_db(kset):
 
 def random_dna(rng, n, alphabet="ACGT"):
     return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+def multiset_text(keys, counts, k):
+    """(keys[n, W] uint64 sorted by k-mer, counts[n]) -> the sorted "KMER<TAB>count<LF>" text of a dump -s."""
+    alpha = "ACGT"
+    out = []
+    for i in range(keys.shape[0]):
+        code = int(keys[i, 0]) | ((int(keys[i, 1]) << 64) if keys.shape[1] == 2 else 0)
+        out.append("".join(alpha[(code >> (2 * (k - 1 - j))) & 3] for j in range(k)) + "\t" + str(int(counts[i])) + "\n")
+    return "".join(out)
+
+
+def check_multiset_case(case, keys, counts, cs):
+    """One case of tests/golden/kmer_multiset.json (the reference's own get_canonical_kmer over
+    process_read_into_kmers, Counter'ed) against an implementation's sorted (keys, counts); `cs` is the counter
+    ceiling the implementation ran with (it must not be reached unless the case says so)."""
+    import hashlib
+    k = case["k"]
+    assert keys.shape[0] == case["distinct"], (case["kind"], k, keys.shape[0], case["distinct"])
+    if case["max_count"] <= cs:
+        assert int(counts.sum()) == case["total"]
+        text = multiset_text(keys, counts, k)
+        assert hashlib.sha256(text.encode()).hexdigest() == case["sha256"], (case["kind"], k, len(case["seq"]))
+        if "multiset" in case:
+            assert text == "".join(f"{km}\t{c}\n" for km, c in case["multiset"])
+    else:   # saturating counters (KMC's documented -cs; not a reference-pinned rule): the k-mer set still has to agree
+        assert "multiset" not in case or [km for km, _ in case["multiset"]] == [ln.split("\t")[0] for ln in multiset_text(keys, counts, k).splitlines()]
