@@ -1832,7 +1832,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
 static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                       const int* group_of, int ngroups, int k, u32 cs, uint64_t* within_hist,
                       uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, kh_set** across_set,
-                      bool* done, u32 nwaves = 1, double s_scale = 1.0, double* want_scale = nullptr) {
+                      bool* done, u32 nwaves = 1, double s_scale = 1.0, double* want_scale = nullptr, u32 fan_hint = 0) {
     *done = false;
     if (want_scale) *want_scale = 0.0;
     const int W = k <= 32 ? 1 : 2;
@@ -1875,7 +1875,7 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     struct SetsGuard { std::vector<kh_set*>& v; ~SetsGuard() { for (auto* s : v) kh_set_free(s); } } sets_guard{wave_sets};
     for (u32 wave = 0; wave < nwaves; ++wave) {
     GridBuild gb;
-    gb.fan = fan;
+    gb.fan = std::max(fan, fan_hint);   // (fan_hint: genomes that are related although every one is a group of its own here)
     gb.wave = wave;
     gb.nwaves = nwaves;
     gb.s_scale = s_scale;
@@ -2058,27 +2058,70 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
         std::vector<int> gcount(ngroups, 0);
         for (int i = 0; i < nseq; ++i) { gbases[group_of[i]] += lens[i]; gcount[group_of[i]]++; }
         std::vector<int> batch_end;      // group index one past each batch
+        std::vector<char> batch_big;     // the batch is ONE group of more than 64 genomes (exp1_big_group)
         bool applicable = true;
         {
             u64 acc_b = 0;
             int acc_n = 0, acc_g = 0, acc_bins = 0;
             for (int g = 0; g < ngroups && applicable; ++g) {
-                if (gcount[g] > KH_TAG_MAX_OPS || gcount[g] == 0) { applicable = false; break; }
+                if (gcount[g] == 0) { applicable = false; break; }
+                if (gcount[g] > KH_TAG_MAX_OPS) {   // wider than the genome mask: a batch of its own, taken in sub-batches
+                    if (acc_n) { batch_end.push_back(g); batch_big.push_back(0); acc_b = 0; acc_n = acc_g = acc_bins = 0; }
+                    batch_end.push_back(g + 1);
+                    batch_big.push_back(1);
+                    continue;
+                }
                 // (a batch above the memory budget is run as key-range waves, see below: groups are
                 // only split into batches by the width of the genome mask)
                 const bool fits = acc_n + gcount[g] <= KH_TAG_MAX_OPS && acc_g + 1 <= KH_TAG_MAX_OPS &&
                                   acc_bins + gcount[g] + 1 + (acc_g + 2) <= KH_TAG_MAX_BINS &&
                                   (acc_b + gbases[g] <= fbudget || acc_n == 0);
-                if (!fits) { batch_end.push_back(g); acc_b = 0; acc_n = acc_g = acc_bins = 0; }
+                if (!fits) { batch_end.push_back(g); batch_big.push_back(0); acc_b = 0; acc_n = acc_g = acc_bins = 0; }
                 acc_b += gbases[g]; acc_n += gcount[g]; acc_g += 1; acc_bins += gcount[g] + 1;
             }
-            batch_end.push_back(ngroups);
+            if (acc_n || batch_end.empty()) { batch_end.push_back(ngroups); batch_big.push_back(0); }
         }
         // a batch whose bases exceed the budget: key-range waves (HBM-spill partitioning of BASELINE
         // configs[4]) — every wave re-extracts the batch's bases but keeps one slice of the key space,
         // so the memory in flight is 1/waves of the keys and the histograms of the waves add up
         auto waves_for = [&](u64 bases) -> u32 { return (u32)std::max<u64>(1, (bases + fbudget - 1) / fbudget); };
-        if (applicable && batch_end.size() == 1) {
+        // One group of more than 64 genomes (exp_type_1.smk:36-61 lists whatever data/dataset_N holds): sub-batches of
+        // up to 64 genomes, each a fused build + tagged union in which every genome is a group of its own, so that the
+        // set a sub-batch emits carries "in how many of its genomes"; one counter-summing union of those sets is the
+        // group's step_3 database (its histogram fused: step_4).
+        auto big_group = [&](int g, uint64_t* whist, uint64_t* dist_out /* [nseq] or null */, kh_set** group_set, bool* done) -> int {
+            *done = false;
+            std::vector<int> members;
+            for (int i = 0; i < nseq; ++i)
+                if (group_of[i] == g) members.push_back(i);
+            std::vector<kh_set*> subs;
+            struct G { std::vector<kh_set*>& v; ~G() { for (auto* x : v) kh_set_free(x); } } guard{subs};
+            for (size_t i0 = 0; i0 < members.size(); i0 += KH_TAG_MAX_OPS) {
+                const size_t m = std::min<size_t>(KH_TAG_MAX_OPS, members.size() - i0);
+                std::vector<const uint8_t*> bs(m);
+                std::vector<uint64_t> bl(m), bd(m, 0);
+                std::vector<int> bg(m);
+                u64 sb = 0;
+                for (size_t j = 0; j < m; ++j) { bs[j] = seqs[members[i0 + j]]; bl[j] = lens[members[i0 + j]]; bg[j] = (int)j; sb += bl[j]; }
+                kh_set* aset = nullptr;
+                bool d = false;
+                double scale = 0.0;
+                KHCHK(exp1_fused(c, (int)m, bs.data(), bl.data(), on_device, bg.data(), (int)m, k, 0x7fffffffu, nullptr, nullptr,
+                                 hist_len, bd.data(), &aset, &d, waves_for(sb), 1.0, &scale, (u32)m));
+                if (!d && scale > 1.0 && scale < 16.0)   // one more try with finer slots
+                    KHCHK(exp1_fused(c, (int)m, bs.data(), bl.data(), on_device, bg.data(), (int)m, k, 0x7fffffffu, nullptr, nullptr,
+                                     hist_len, bd.data(), &aset, &d, waves_for(sb), scale, nullptr, (u32)m));
+                if (!d) return KH_OK;
+                subs.push_back(aset);
+                if (dist_out)
+                    for (size_t j = 0; j < m; ++j) dist_out[members[i0 + j]] = bd[j];
+            }
+            if (group_set) KHCHK(kh_union_sum(c, subs.data(), (int)subs.size(), cs, group_set, whist, whist ? hist_len : 0));
+            else if (whist) KHCHK(kh_union_histogram(c, subs.data(), (int)subs.size(), cs, whist, hist_len));
+            *done = true;
+            return KH_OK;
+        };
+        if (applicable && batch_end.size() == 1 && !batch_big[0]) {
             u64 all_bases = 0;
             for (int g = 0; g < ngroups; ++g) all_bases += gbases[g];
             bool done = false;
@@ -2110,6 +2153,13 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
                 std::vector<uint64_t> wtmp(within_hist ? (size_t)ngroups * hist_len : 0), dtmp(nseq, 0), atmp(hist_len, 0);
                 for (size_t b = 0; b < batch_end.size() && ok2; ++b) {
                     const int g1b = batch_end[b];
+                    if (batch_big[b]) {
+                        bool done = false;
+                        KHCHK(big_group(g0b, within_hist ? wtmp.data() + (size_t)g0b * hist_len : nullptr, dtmp.data(), nullptr, &done));
+                        if (!done) { ok2 = false; break; }
+                        g0b = g1b;
+                        continue;
+                    }
                     std::vector<int> idx;
                     for (int i = 0; i < nseq; ++i)
                         if (group_of[i] >= g0b && group_of[i] < g1b) idx.push_back(i);
@@ -2144,6 +2194,22 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
             int g0 = 0;
             for (size_t b = 0; b < batch_end.size() && ok; ++b) {
                 const int g1 = batch_end[b];
+                if (batch_big[b]) {   // its across-group set: the group's k-mers, each counted once
+                    kh_set* gs = nullptr;
+                    bool done = false;
+                    int r = big_group(g0, within_hist ? within_hist + (size_t)g0 * hist_len : nullptr, distinct_per_seq,
+                                      want_across ? &gs : nullptr, &done);
+                    if (r == KH_OK && done && gs) {
+                        kh_set* one = nullptr;
+                        r = kh_set_counts(c, gs, 1, &one);
+                        kh_set_free(gs);
+                        if (r == KH_OK) asets.push_back(one);
+                    }
+                    if (r != KH_OK) { drop(); return r; }
+                    if (!done) { ok = false; break; }
+                    g0 = g1;
+                    continue;
+                }
                 std::vector<int> idx;
                 for (int i = 0; i < nseq; ++i)
                     if (group_of[i] >= g0 && group_of[i] < g1) idx.push_back(i);

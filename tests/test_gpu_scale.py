@@ -203,3 +203,66 @@ def test_cfg3_full_size_10x10x5mbp(eng, k):
     assert (got["across_hist"] == want["across_hist"]).all()
     check_reference_invariants(eng, seqs, group_of, got, k)
     eng.trim()
+
+
+def big_group_set(sizes, length):
+    """One species per group, `sizes[g]` genomes in group g (the synthetic generator has no limit on genomes)."""
+    from khoice_amd import synth
+    seqs, group_of = [], []
+    for g, n in enumerate(sizes):
+        anc = synth.ancestor(g + 1, length)
+        for j in range(n):
+            seqs.append(synth.clean_text(synth.genome_records(g + 1, j, length, anc)))
+            group_of.append(g)
+    return seqs, group_of
+
+
+@pytest.mark.parametrize("k", [31, 41])
+def test_groups_of_more_than_64_genomes_stay_fused(eng, k):
+    """BASELINE configs[4] shape ("all available genomes": exp_type_1.smk:36-61 lists whatever data/dataset_N holds):
+    groups of 10, 70, 200 and 300 genomes.  Every histogram and distinct count equals the C restatement's, and the
+    work was done by the fused forms (tagged unions over sub-batches of 64 genomes + the super-k-mer passes), not
+    by per-genome databases."""
+    from oracle import c_oracle as CO
+    seqs, group_of = big_group_set([10, 70, 200, 300], 50_000)
+    order = np.random.default_rng(5).permutation(len(seqs))          # groups interleaved, as a caller may pass them
+    seqs = [seqs[i] for i in order]
+    group_of = [group_of[i] for i in order]
+    eng.profile(True)
+    eng.stats_reset()
+    got = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=5001)
+    st = eng.stats()
+    eng.profile(False)
+    want = CO.exp1(seqs, group_of, k, cs=5000, hist_len=5001, nthreads=8)
+    assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+    assert (got["within_hist"] == want["within_hist"]).all()
+    assert (got["across_hist"] == want["across_hist"]).all()
+    assert int(got["within_hist"][3, 150:].sum()) > 0 and int(got["within_hist"][2, 100:].sum()) > 0   # k-mers most of a big group shares
+    kern = st["kernels"]
+    assert kern["union_tagged"]["launches"] >= 2 + 4 + 5        # sub-batches of the three big groups
+    assert kern["skm_union"]["launches"] >= 2                   # the 10-genome group, and the pass by group
+    assert st["builds"] == len(seqs)                            # nothing was built twice (no fall-back)
+    # a small saturation value goes through the same sums
+    got3 = eng.exp1_run(seqs, group_of, k, cs=3, hist_len=8)
+    want3 = CO.exp1(seqs, group_of, k, cs=3, hist_len=8, nthreads=8)
+    assert (got3["within_hist"] == want3["within_hist"]).all() and (got3["across_hist"] == want3["across_hist"]).all()
+
+
+def test_configs3_twenty_groups_on_one_gpu(eng):
+    """BASELINE configs[3]'s workload (20 species x 5 genomes x 5 Mbp, k = 31) through kh_exp1_run on ONE GPU: 100 genomes
+    = batches of whole groups + the pass by group.  What stays unmeasured for that config is the 8-way sharding."""
+    from khoice_amd import synth
+    from oracle import c_oracle as CO
+    items = synth.species_set(20, 5, 5_000_000)
+    seqs = [t for _, _, t in items]
+    group_of = [s - 1 for s, _, _ in items]
+    eng.profile(True)
+    eng.stats_reset()
+    got = eng.exp1_run(seqs, group_of, 31, cs=5000, hist_len=5001)
+    st = eng.stats()
+    eng.profile(False)
+    want = CO.exp1(seqs, group_of, 31, cs=5000, hist_len=5001, nthreads=0)
+    assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+    assert (got["within_hist"] == want["within_hist"]).all()
+    assert (got["across_hist"] == want["across_hist"]).all()
+    assert st["kernels"]["skm_union"]["launches"] == 3 and st["retries"] == 0     # two batches of ten groups + the pass by group

@@ -5,6 +5,10 @@
         (one call for all 25), K4 histogram (the CPU baseline lives in bench.py alone)
   cfg3  10 species x 10 genomes x 5 Mbp, k in {15, 21, 27, 31, 41}: fused within-group occurrence
         (steps 1-4 of exp_type_1.smk, `kh_exp1_run` without the across-group step)
+  cfg4  20 species x 5 genomes x 5 Mbp, k = 31, steps 1-8 on ONE GPU (the config's 8-way sharding is the
+        driver's to measure)
+  cfg5  the shape of configs[4] ("all available genomes": groups far above the 64-genome mask): 5 species with
+        10 / 70 / 200 / 70 / 10 genomes of 1 Mbp, k = 31 and k = 63, steps 1-8
 
 Inputs are resident in HBM; every figure is the median of `--reps` timed repetitions after one
 warm-up.  One JSON object on stdout (committed as profiles/rNN_configs.json).
@@ -79,6 +83,45 @@ def main():
                      "distinct_kmers": d, "distinct_per_s": round(d / t, 1),
                      "bases_per_s": round(sum(n for _, n in seqs) / t, 1)})
     out["cfg3"] = {"workload": f"10 x 10 x {a.length} bp, steps 1-4 (within-group occurrence)", "per_k": rows}
+    del dev
+    eng.trim()
+
+    # ---------------------------------------------------------------- cfg4 (one GPU)
+    items = synth.species_set(20, 5, a.length)
+    dev, seqs = resident(items)
+    group_of = [s - 1 for s, _, _ in items]
+    r0 = eng.stats()["retries"]
+    t, res = timed(lambda: eng.exp1_run(seqs, group_of, 31, cs=5000, hist_len=5001), max(2, a.reps // 2), eng.sync)
+    d = int(res["distinct_per_seq"].sum())
+    out["cfg4_one_gpu"] = {"workload": f"20 x 5 x {a.length} bp, k=31, steps 1-8", "ms": round(1e3 * t, 3), "distinct_kmers": d,
+                           "distinct_per_s": round(d / t, 1), "replans_per_run": (eng.stats()["retries"] - r0) / (1 + max(2, a.reps // 2))}
+    del dev
+    eng.trim()
+
+    # ---------------------------------------------------------------- cfg5 shape: groups above the 64-genome mask
+    sizes = [10, 70, 200, 70, 10]
+    length5 = min(a.length, 1_000_000)
+    texts, group_of = [], []
+    for g, n in enumerate(sizes):
+        anc = synth.ancestor(g + 1, length5)
+        for j in range(n):
+            texts.append(synth.clean_text(synth.genome_records(g + 1, j, length5, anc)))
+            group_of.append(g)
+    dev = [torch.from_numpy(np.frombuffer(t, dtype=np.uint8).copy()).cuda() for t in texts]
+    seqs = [(x.data_ptr(), x.numel()) for x in dev]
+    rows = []
+    for k in (31, 63):
+        r0 = eng.stats()["retries"]
+        eng.profile(True)
+        eng.stats_reset()
+        t, res = timed(lambda: eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=5001), 2, eng.sync)
+        st = eng.stats()
+        eng.profile(False)
+        d = int(res["distinct_per_seq"].sum())
+        rows.append({"k": k, "ms": round(1e3 * t, 3), "distinct_kmers": d, "distinct_per_s": round(d / t, 1),
+                     "bases_per_s": round(sum(n for _, n in seqs) / t, 1), "replans_per_run": st["retries"] / 3,
+                     "kernel_launches_per_run": {n: v["launches"] // 3 for n, v in st["kernels"].items() if v["launches"]}})
+    out["cfg5_shape"] = {"workload": f"groups of {sizes} genomes x {length5} bp, steps 1-8", "genomes": len(texts), "per_k": rows}
     print(json.dumps(out))
     eng.close()
 
