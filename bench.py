@@ -11,8 +11,8 @@ Inputs (cleaned sequence text, 1 byte per base) are resident in HBM before the t
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU; every rank owns its own 10 species (weak scaling); steps 1-6 need
-no communication, step 7-8 exchanges the group sets by key range over RCCL (all-to-all) and
-all-reduces the histogram (khoice_amd/dist.py).
+no communication, step 7-8 exchanges minimizer records by slot range over RCCL (all-to-all; key sets by key
+range outside 20 <= k <= 32) and all-reduces the histogram (khoice_amd/dist.py).
 
 value = (sum over all genomes of all ranks of their distinct canonical k-mers) / step time.
 """
@@ -292,6 +292,10 @@ def main():
         "issue_roofline": issue,
         "kernel_ms_per_step": kernel_ms,
         "replans": st["retries"], "order_fallbacks": st.get("order_fallbacks", 0),
+        # N > 1: how steps 7-8 crossed the ranks ("records": every rank in the super-k-mer form, minimizer records
+        # exchanged by slot range; "sets": key sets exchanged by key range) — a rank's step is then TWO passes over its
+        # k-mers (within-group locally, across-group on exchanged data), not the one pass of the N = 1 line
+        "exchange_form": (res.get("exchange", "sets") if use_dist else None),
         "setup_seconds": round(gen_s, 1),
     }
 

@@ -245,6 +245,25 @@ int kh_across_exchange_histogram(kh_ctx *ctx, kh_comm *comm, const kh_set *local
 void kh_mix_host(int k, const uint64_t *key_words, uint64_t *out_words);
 void kh_unmix_host(int k, const uint64_t *key_words, uint64_t *out_words);
 
+/* ---------------------------------------------------------------- steps 7-8 across ranks, exchange of records
+ * (workflow/rules/exp_type_1.smk:243-259 when the groups live on several GPUs; 20 <= k <= 32).
+ * kh_skm_exchange_plan: the slot geometry all ranks must share, from numbers they agreed on (the largest rank's number
+ *   of k-mer positions, the largest group of any rank).
+ * kh_skm_pack: this rank's genomes -> minimizer records tagged with the LOCAL group number tag_of[i] (0..31), identical
+ *   records merged, packed by owner of their slot into CALLER-ALLOCATED device buffers: rec_out [nparts][part_cap] x 16
+ *   bytes, mask_out [nparts][part_cap], count_out / off_out [nparts][slots_per_part] (records of a slot and where they
+ *   start in their part); part_n[p] (host) = records for part p.
+ * kh_skm_phased_histogram: on the owner, the pieces received (one per source rank, device pointers) -> hist[c] = number of
+ *   distinct k-mers of this rank's slots that occur in c groups of all ranks (c saturating at cs). */
+int kh_skm_exchange_plan(kh_ctx *ctx, int k, uint64_t positions_max, uint32_t fan_max, int nparts, uint32_t *nslots,
+                         uint32_t *slots_per_part, uint64_t *part_cap);
+int kh_skm_pack(kh_ctx *ctx, int nseq, const uint8_t *const *seqs, const uint64_t *lens, int on_device, const int *tag_of,
+                int k, uint32_t nslots, int nparts, uint64_t part_cap, void *rec_out, uint32_t *mask_out,
+                uint32_t *count_out, uint32_t *off_out, uint64_t *part_n);
+int kh_skm_phased_histogram(kh_ctx *ctx, int k, int npieces, const void *const *recs, const uint32_t *const *masks,
+                            const uint32_t *const *counts, const uint32_t *const *offs, uint32_t nslots, uint32_t cs,
+                            uint64_t *hist, uint32_t hist_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1529,9 +1529,21 @@ static int group_union_incremental(kh_ctx* c, const std::vector<int>& members, c
 // by_group: the operands of the union are the GROUPS (every record carries its genome's group number): only the
 // across-group histogram comes out — the second pass of a run over more than 64 genomes, whose batches of
 // whole groups have answered the within-group questions.
+// records_only (the exchange form of the multi-GPU step): stop behind the regroup and hand the records by slot out —
+// with force_slots slots, the number all ranks agreed on (slots are a global function of the minimizer).
+struct SkmRecords {
+    u32 force_slots = 0;
+    DevBuf* reg2 = nullptr;     // out: [nslots][cap2] records
+    DevBuf* ws = nullptr;       // out: workspace that holds cur2
+    const u32* cur2 = nullptr;  // out: [nslots] records per slot
+    u32 nslots = 0, cap2 = 0;
+    u64 records = 0;            // out: records written
+    ~SkmRecords() { buf_unref(reg2); buf_unref(ws); }
+};
 static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                     const int* group_of, int ngroups, int k, u32 cs, uint64_t* within_hist,
-                    uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, bool* done, bool by_group = false) {
+                    uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, bool* done, bool by_group = false,
+                    SkmRecords* rec_out = nullptr) {
     *done = false;
     if (k < KH_SKM_MIN_K || k > KH_SKM2_MAX_K || getenv("KHOICE_NO_SKM")) return KH_OK;
     const bool two = k > KH_SKM_MAX_K;   // two-word keys: 32-byte records, kh_skm2.hip
@@ -1611,7 +1623,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         if (c2 <= (double)max_cap2 || mean <= 256) break;
         mean = std::max<u32>(256, (u32)((double)mean * (double)max_cap2 / c2 * 0.98));
     }
-    const u64 nslots64 = std::max<u64>(1, (total_pos + mean - 1) / mean);
+    const u64 nslots64 = rec_out && rec_out->force_slots ? rec_out->force_slots : std::max<u64>(1, (total_pos + mean - 1) / mean);
     // coarse buckets: 256 keep the scatter's runs long; inputs past 256 x 512 slots (> 400 M k-mers) take 512
     const u32 max_coarse = (two || nslots64 > (u64)KH_SKM_MAX_COARSE * KH_SKM_MAX_FINE) ? KH_SKM2_MAX_COARSE : KH_SKM_MAX_COARSE;
     if (nslots64 > (u64)max_coarse * (two ? KH_SKM2_MAX_FINE : KH_SKM_MAX_FINE)) return KH_OK;
@@ -1754,6 +1766,22 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
 #ifdef KH_STAMPS
     kh_debug_set_stamps_skm(d_stamps.as<u64>());
 #endif
+    if (rec_out) {   // the records by slot are what the caller wants
+        HIPCHK(hipGetLastError());
+        u32 h_ctl[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(h_ctl, job.ctl, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER)) { c->stat.retries++; return KH_OK; }
+        c->stat.skm_records += h_ctl[2];
+        rec_out->records = h_ctl[2];
+        rec_out->reg2 = d_reg2.b; d_reg2.b = nullptr;
+        rec_out->ws = d_ws.b; d_ws.b = nullptr;
+        rec_out->cur2 = job.cur2;
+        rec_out->nslots = nslots;
+        rec_out->cap2 = cap2;
+        *done = true;
+        return KH_OK;
+    }
     c->prof_begin(KC_SKM_UNION);
     if (two) kh_launch_skm2_union(job, cs, st);
     else kh_launch_skm_union(job, cs, ugrid, st);
@@ -2369,6 +2397,143 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
         for (int g = 0; g < ngroups; ++g) { group_sets[g] = unions[g]; unions[g] = nullptr; }
     if (across_set) { *across_set = across; across = nullptr; }
     cleanup();
+    return KH_OK;
+}
+
+// ------------------------------------------------------------------------------ exchange form of steps 7-8
+// Multi-GPU (khoice_amd/dist.py): every rank turns its genomes into records tagged with the LOCAL group number,
+// merges identical ones and packs them by the rank that owns their slot (kh_skm_pack); the packed arrays travel
+// (all-to-all); the owner runs ONE phased union over the pieces it received (kh_skm_phased_histogram) and the small
+// histograms are all-reduced.  Slot geometry must be the same on all ranks: kh_skm_exchange_plan works it out from
+// numbers the ranks have agreed on (the largest rank's k-mer positions, the largest group).
+static bool skm_exchange_k(int k) { return k >= KH_SKM_MIN_K && k <= KH_SKM_MAX_K; }
+
+extern "C" int kh_skm_exchange_plan(kh_ctx* c, int k, uint64_t positions_max, uint32_t fan_max, int nparts, uint32_t* nslots,
+                                    uint32_t* slots_per_part, uint64_t* part_cap) {
+    if (!c || !nslots || !slots_per_part || !part_cap || nparts < 1) return kh_fail(KH_E_ARG, "kh_skm_exchange_plan: bad argument");
+    if (!skm_exchange_k(k)) return kh_fail(KH_E_ARG, "the exchange form takes k = %d .. %d", KH_SKM_MIN_K, KH_SKM_MAX_K);
+    const int m15w = k - 15 + 1;
+    const int m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;
+    const u32 w = (u32)(k - m + 1);
+    // k-mer instances per slot and rank: the pack kernel takes 1024 records of a slot; the owner's table (4096 entries)
+    // has to hold the slot's distinct k-mers of ALL ranks — sized for unrelated groups: nparts x the per-rank mean
+    // below three quarters of it
+    const double per_kmer = 2.0 / (double)(w + 1) + 1.0 / 48.0;
+    (void)fan_max;
+    // k-mer instances per slot and rank.  The owner's table (4096 entries) takes ~3000 instances per round: with
+    // groups of related genomes about 0.55 of a rank's instances survive the merge of identical records, so
+    // 2600 / (0.55 x nparts) per rank keeps the owner at one round (unrelated genomes: two).  A rank's slot must also
+    // fit the pack kernel's 1024 records, and the two partition levels give 512 x 512 slots at most (beyond: the
+    // slots grow and the owner takes more rounds).
+    double mean = std::min(2600.0 / (0.55 * (double)nparts), (1024.0 - 128.0) / (1.7 * per_kmer));
+    if (const char* e = getenv("KHOICE_SKM_EXCHANGE_MEAN")) mean = std::max(16.0, atof(e));   // tests: rounds on the owner
+    u64 ns = std::max<u64>((u64)nparts, (u64)((double)std::max<u64>(1, positions_max) / mean) + 1);
+    ns = std::min<u64>(ns, (u64)KH_SKM2_MAX_COARSE * KH_SKM_MAX_FINE);
+    if ((double)positions_max / (double)ns * per_kmer * 1.7 + 128.0 > 1024.0)
+        return kh_fail(KH_E_CAPACITY, "too many k-mers per rank for the exchange form (%llu positions)", (unsigned long long)positions_max);
+    *nslots = (u32)ns;
+    *slots_per_part = (u32)((ns + nparts - 1) / nparts);
+    *part_cap = ((u64)((double)positions_max * per_kmer * 1.3 / nparts) + 8192 + 63) & ~63ull;
+    return KH_OK;
+}
+
+extern "C" int kh_skm_pack(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
+                           const int* tag_of, int k, uint32_t nslots, int nparts, uint64_t part_cap, void* rec_out,
+                           uint32_t* mask_out, uint32_t* count_out, uint32_t* off_out, uint64_t* part_n) {
+    if (!c || !seqs || !lens || !tag_of || nseq <= 0 || nparts < 1 || !rec_out || !mask_out || !count_out || !off_out || !part_n)
+        return kh_fail(KH_E_ARG, "kh_skm_pack: bad argument");
+    if (!skm_exchange_k(k)) return kh_fail(KH_E_ARG, "the exchange form takes k = %d .. %d", KH_SKM_MIN_K, KH_SKM_MAX_K);
+    int ntags = 0;
+    for (int i = 0; i < nseq; ++i) {
+        if (tag_of[i] < 0 || tag_of[i] >= 32) return kh_fail(KH_E_ARG, "kh_skm_pack: tag %d outside 0..31", tag_of[i]);
+        ntags = std::max(ntags, tag_of[i] + 1);
+    }
+    HIPCHK(hipSetDevice(c->dev));
+    hipStream_t st = c->st;
+    SkmRecords rec;
+    rec.force_slots = nslots;
+    bool done = false;
+    {   // every tag needs a sequence for the geometry code (groups without genomes are refused there): tags are dense here
+        std::vector<int> seen(ntags, 0);
+        for (int i = 0; i < nseq; ++i) seen[tag_of[i]] = 1;
+        for (int t = 0; t < ntags; ++t)
+            if (!seen[t]) return kh_fail(KH_E_ARG, "kh_skm_pack: tag %d has no sequence", t);
+    }
+    KHCHK(exp1_skm(c, nseq, seqs, lens, on_device, tag_of, ntags, k, 1, nullptr, nullptr, 2, nullptr, &done, /*by_group=*/true, &rec));
+    if (!done) return kh_fail(KH_E_CAPACITY, "kh_skm_pack: the records did not fit their regions (low-complexity input?)");
+    const u32 spp = (rec.nslots + (u32)nparts - 1) / (u32)nparts;
+    Tmp d_ctl;
+    TMP_ALLOC(d_ctl, c, 64 + 4 * (size_t)nparts);
+    HIPCHK(hipMemsetAsync(d_ctl.b->p, 0, 64 + 4 * (size_t)nparts, st));
+    HIPCHK(hipMemsetAsync(count_out, 0, 4 * (size_t)spp * nparts, st));   // (slots past the last one: nothing)
+    HIPCHK(hipMemsetAsync(off_out, 0, 4 * (size_t)spp * nparts, st));
+    KhSkmPackJob job;
+    job.reg2 = reinterpret_cast<const uint4*>(rec.reg2->p);
+    job.cur2 = rec.cur2;
+    job.out_rec = static_cast<uint4*>(rec_out);
+    job.out_mask = mask_out;
+    job.part_cursor = reinterpret_cast<u32*>(d_ctl.as<u8>() + 64);
+    job.slot_count = count_out;
+    job.slot_off = off_out;
+    job.ctl = d_ctl.as<u32>();
+    job.part_cap = part_cap;
+    job.cap2 = rec.cap2;
+    job.nslots = rec.nslots;
+    job.spp = spp;
+    c->prof_begin(KC_SKM_UNION);
+    kh_launch_skm_pack(job, st);
+    c->prof_end();
+    HIPCHK(hipGetLastError());
+    std::vector<u32> h(16 + nparts);
+    HIPCHK(hipMemcpyAsync(h.data(), d_ctl.b->p, 64 + 4 * (size_t)nparts, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (h[0] & KH_ERR_ORDER) return kh_fail(KH_E_INTERNAL, "kh_skm_pack: a record carried a tag above 31");
+    if (h[0] & KH_ERR_CAPACITY) return kh_fail(KH_E_CAPACITY, "kh_skm_pack: a slot or a part overflowed");
+    for (int p = 0; p < nparts; ++p) part_n[p] = h[16 + p];
+    return KH_OK;
+}
+
+extern "C" int kh_skm_phased_histogram(kh_ctx* c, int k, int npieces, const void* const* recs, const uint32_t* const* masks,
+                                       const uint32_t* const* counts, const uint32_t* const* offs, uint32_t nslots, uint32_t cs,
+                                       uint64_t* hist, uint32_t hist_len) {
+    if (!c || npieces < 1 || !recs || !masks || !counts || !offs || !hist || hist_len < 2 || cs < 1)
+        return kh_fail(KH_E_ARG, "kh_skm_phased_histogram: bad argument");
+    if (!skm_exchange_k(k)) return kh_fail(KH_E_ARG, "the exchange form takes k = %d .. %d", KH_SKM_MIN_K, KH_SKM_MAX_K);
+    HIPCHK(hipSetDevice(c->dev));
+    hipStream_t st = c->st;
+    const size_t off_pieces = 64, off_hist = (off_pieces + sizeof(KhSkmPiece) * (size_t)npieces + 63) & ~(size_t)63;
+    const size_t ws_bytes = off_hist + 8 * (size_t)hist_len;
+    Tmp d_ws;
+    TMP_ALLOC(d_ws, c, ws_bytes);
+    std::vector<u8> up(off_hist, 0);
+    KhSkmPiece* hp = reinterpret_cast<KhSkmPiece*>(up.data() + off_pieces);
+    for (int i = 0; i < npieces; ++i) {
+        hp[i].rec = static_cast<const uint4*>(recs[i]);
+        hp[i].mask = masks[i];
+        hp[i].count = counts[i];
+        hp[i].off = offs[i];
+    }
+    HIPCHK(hipMemsetAsync(d_ws.b->p, 0, ws_bytes, st));
+    HIPCHK(hipMemcpyAsync(d_ws.b->p, up.data(), off_hist, hipMemcpyHostToDevice, st));
+    KhSkmPhasedJob job;
+    job.pieces = reinterpret_cast<const KhSkmPiece*>(d_ws.as<u8>() + off_pieces);
+    job.hist = reinterpret_cast<unsigned long long*>(d_ws.as<u8>() + off_hist);
+    job.ctl = d_ws.as<u32>();
+    job.npieces = (u32)npieces;
+    job.nslots = nslots;
+    job.hist_len = hist_len;
+    job.cs = cs;
+    job.k = k;
+    c->prof_begin(KC_SKM_UNION);
+    kh_launch_skm_phased(job, std::min<u32>(std::max<u32>(1, nslots), 2u * (u32)std::max(1, c->cus)), st);
+    c->prof_end();
+    HIPCHK(hipGetLastError());
+    u32 h_ctl[4];
+    HIPCHK(hipMemcpyAsync(h_ctl, d_ws.b->p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hist, d_ws.as<u8>() + off_hist, 8 * (size_t)hist_len, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (h_ctl[0] & KH_ERR_CAPACITY) return kh_fail(KH_E_CAPACITY, "kh_skm_phased_histogram: a slot held more k-mers than its table");
+    c->stat.setops++;
     return KH_OK;
 }
 

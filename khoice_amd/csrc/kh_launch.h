@@ -165,6 +165,36 @@ void kh_launch_skm_scatter(const KhSkmJob& job, u32 ntiles, hipStream_t st);
 void kh_launch_skm_regroup(const KhSkmJob& job, hipStream_t st);
 void kh_launch_skm_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st);   // persistent: grid workgroups walk the slots
 u32 kh_skm_union_per_cu(u32 table);   // workgroups of the union that fit a CU
+// ---- the exchange form of the across-group step (multi-GPU; kh_skm.hip k_skm_pack / k_skm_phased)
+struct KhSkmPackJob {
+    const uint4* reg2;              // [nslots][cap2] this rank's records by slot (tag = local group, < 32)
+    const u32* cur2;                // [nslots]
+    uint4* out_rec;                 // [nparts][part_cap] the records that travel, by owner of their slot
+    u32* out_mask;                  // [nparts][part_cap] their masks of local groups
+    u32* part_cursor;               // [nparts] zeroed
+    u32* slot_count;                // [nslots] records that travel
+    u32* slot_off;                  // [nslots] where they start in their part's array
+    u32* ctl;                       // [0] error bits
+    u64 part_cap;
+    u32 cap2, nslots, spp;          // spp: slots per part (slot s belongs to part s / spp)
+};
+struct KhSkmPiece {                 // what one source rank sent for this rank's slots
+    const uint4* rec;
+    const u32* mask;
+    const u32* count;               // [nslots of this rank]
+    const u32* off;                 // [nslots of this rank] first record of the slot in `rec`
+};
+struct KhSkmPhasedJob {
+    const KhSkmPiece* pieces;       // device array [npieces]
+    unsigned long long* hist;       // [hist_len], zeroed
+    u32* ctl;                       // [0] error bits
+    u32 npieces, nslots, hist_len, cs;
+    int k;
+};
+size_t kh_skm_pack_lds_bytes();
+size_t kh_skm_phased_lds_bytes();
+void kh_launch_skm_pack(const KhSkmPackJob& job, hipStream_t st);
+void kh_launch_skm_phased(const KhSkmPhasedJob& job, u32 grid, hipStream_t st);
 // the same three steps for two-word keys (kh_skm2.hip): 32-byte records (two uint4 per record in reg1 / reg2)
 constexpr int KH_SKM2_MAX_K = 63;         // k = 64: the all-ones low key word is a k-mer (A^32 T^32)
 constexpr u32 KH_SKM2_MAX_COARSE = 512;

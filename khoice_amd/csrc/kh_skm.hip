@@ -803,6 +803,299 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
 }
 
 // ------------------------------------------------------------------------------------------
+// The exchange form (multi-GPU step 7-8): slots are a GLOBAL function of the minimizer, so ranks
+// exchange RECORDS by slot range instead of key sets.
+//
+//   k_skm_pack     one workgroup per slot of this rank's records (tag = local group, < 32): identical records of a
+//                  group are the same piece of sequence in several of its genomes — only one travels; identical
+//                  records of different groups merge into one with a mask of groups.  The survivors go, with their
+//                  32-bit masks, to the record array of the rank that owns the slot (one returning global atomic
+//                  per slot); per slot: how many, and where.
+//   k_skm_phased   persistent, one slot at a time: the pieces (one per source rank) are PHASES.  A phase expands
+//                  its records and ORs their masks into the table's low mask plane; between phases every entry
+//                  folds popcount(mask) into its counter (the high plane) and clears the mask: tags of different
+//                  phases are different groups, so the counter ends as "in how many groups of all ranks".
+// ------------------------------------------------------------------------------------------
+constexpr u32 SKM_PK_NT = 1024, SKM_PK_T = 4096;
+size_t kh_skm_pack_lds_bytes() { return (size_t)SKM_PK_NT * 16 + (size_t)SKM_PK_T * 4 + (size_t)SKM_PK_NT * 4 + 64; }
+
+__global__ __launch_bounds__(SKM_PK_NT) void k_skm_pack(const KhSkmPackJob jb) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    constexpr u32 NT = SKM_PK_NT, T = SKM_PK_T;
+    uint4* stage = reinterpret_cast<uint4*>(lds_raw);
+    u32* dd = reinterpret_cast<u32*>(lds_raw + (size_t)NT * 16);
+    u32* rmask = dd + T;
+    u32* scratch = rmask + NT;
+    const u32 tid = threadIdx.x, lane = lane_id();
+    const u32 slot = blockIdx.x;
+    u32 nrec = jb.cur2[slot];
+    nrec = nrec < jb.cap2 ? nrec : jb.cap2;
+    if (nrec > NT) {   // (the host sizes the slots so that this does not happen)
+        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+        nrec = NT;
+    }
+    const uint4 rr = tid < nrec ? (jb.reg2 + (u64)slot * jb.cap2)[tid] : make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4*>(dd)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) { scratch[0] = 0; scratch[1] = 0; }
+    const u32 tg = (rr.w >> 21) & 63u;
+    u32 nj = 0;
+    if (tid < nrec) {
+        nj = rr.w >> 27;
+        stage[tid] = rr;
+        rmask[tid] = 1u << (tg & 31u);
+        if (tg >= 32u) atomicOr(jb.ctl, KH_ERR_ORDER);   // tags of the exchange form are below 32
+    }
+    __syncthreads();
+    bool won = false;
+    if (__builtin_amdgcn_ballot_w64(nj != 0)) {
+        u32 h = rr.x * 0x9E3779B1u ^ rr.y * 0x85EBCA77u ^ rr.z * 0xC2B2AE3Du ^ (rr.w & ~(63u << 21)) * 0x27D4EB2Fu;
+        h ^= h >> 15;
+        h *= 0x2C1B3C6Du;
+        u32 hp = h >> 20;
+        bool pend = nj != 0;
+        while (__builtin_amdgcn_ballot_w64(pend)) {
+            if (pend) {
+                const u32 old = atomicCAS(&dd[hp], 0u, tid + 1u);
+                if (old == 0u) { won = true; pend = false; }
+                else {
+                    const uint4 o = stage[old - 1u];
+                    if (o.x == rr.x && o.y == rr.y && o.z == rr.z && ((o.w ^ rr.w) & ~(31u << 21)) == 0u) {
+                        atomicOr(&rmask[old - 1u], 1u << (tg & 31u));
+                        pend = false;
+                    } else hp = (hp + 1u) & (T - 1u);
+                }
+            }
+        }
+    }
+    // ---- the survivors, in thread order, to the array of the rank that owns the slot
+    const u32 incl = wave_scan_add(won ? 1u : 0u);
+    u32 wbase = 0;
+    if (lane == KH_WAVE - 1 && incl) wbase = atomicAdd(&scratch[0], incl);
+    wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
+    __syncthreads();   // all masks are final, the slot's total is known
+    const u32 nsurv = scratch[0];
+    const u32 part = slot / jb.spp;
+    if (tid == 0) {
+        const u32 base = nsurv ? atomicAdd(&jb.part_cursor[part], nsurv) : 0u;
+        scratch[1] = base;
+        jb.slot_count[slot] = nsurv;
+        jb.slot_off[slot] = base;
+        if ((u64)base + nsurv > jb.part_cap) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+    }
+    __syncthreads();
+    if (won) {
+        const u64 at = (u64)scratch[1] + wbase + incl - 1u;
+        if (at < jb.part_cap) {
+            jb.out_rec[(u64)part * jb.part_cap + at] = rr;
+            jb.out_mask[(u64)part * jb.part_cap + at] = rmask[tid];
+        }
+    }
+}
+
+constexpr u32 SKM_PH_NT = 1024, SKM_PH_T = 4096, SKM_PH_T2 = 128, SKM_PH_MAXCH = 3072, SKM_PH_HBINS = 512;
+constexpr u32 SKM_PH_ROUND = 3072;   // k-mer instances a round of the phased union takes (the table has 4096 entries)
+size_t kh_skm_phased_lds_bytes() {
+    return (size_t)SKM_PH_T * 16 + (size_t)SKM_PH_T2 * 16 + 128 + (size_t)SKM_PH_HBINS * 4 + (size_t)SKM_PH_MAXCH * 2;
+}
+
+__global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJob jb) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    constexpr u32 NT = SKM_PH_NT, T = SKM_PH_T, T2 = SKM_PH_T2, HBITS = 12;
+    constexpr int E = (int)SKM_UE;
+    constexpr u64 EMPTY = ~0ull;
+    u8* p = lds_raw;
+    unsigned long long* tkey = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T * 8;
+    u32* tmlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T * 4;   // the running phase's mask
+    u32* tcnt = reinterpret_cast<u32*>(p);                                 p += (size_t)T * 4;   // tags of the phases before it
+    unsigned long long* okey = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T2 * 8;
+    u32* omlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
+    u32* ocnt = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
+    u32* scratch = reinterpret_cast<u32*>(p);                              p += 128;   // [0] chunks of the phase, [1] entries made, [2] k-mers of the slot
+    u32* lhist = reinterpret_cast<u32*>(p);                                p += (size_t)SKM_PH_HBINS * 4;
+    u16* owner = reinterpret_cast<u16*>(p);
+    const u32 tid0 = threadIdx.x;
+    u32 tid = tid0, lane = lane_id();
+    const int k = jb.k;
+    const u32 kmh = (u32)(kh_mask(2 * k) >> 32), fsh = 64u - 2u * (u32)k, tsh = 2u * (u32)k - 2u, tsh_hi = tsh - 32u;
+    const u32 hbins = jb.hist_len < SKM_PH_HBINS ? jb.hist_len : SKM_PH_HBINS;   // counts below this: LDS; above: global atomics
+    typedef const u32 __attribute__((address_space(4))) * ConstU32;
+    if (tid < SKM_PH_HBINS) lhist[tid] = 0;
+    if (tid < 4) scratch[tid] = 0;
+    __syncthreads();
+    for (u32 slot = blockIdx.x; slot < jb.nslots; slot += gridDim.x) {
+        tid = tid0;
+        asm volatile("" : "+v"(tid));   // (addresses formed from it are worked out where they are used)
+        lane = tid & (KH_WAVE - 1u);
+        // ---- how many k-mer instances the slot holds over all pieces: more than a table takes -> rounds of key subsets
+        {
+            u32 mine = 0;
+            for (u32 ph = 0; ph < jb.npieces; ++ph) {
+                const KhSkmPiece pc = jb.pieces[ph];
+                u32 nrec = ((ConstU32)(unsigned long long)pc.count)[slot];
+                nrec = nrec < NT ? nrec : NT;
+                if (tid < nrec) mine += (pc.rec + ((ConstU32)(unsigned long long)pc.off)[slot])[tid].w >> 27;
+            }
+            if (__builtin_amdgcn_ballot_w64(mine != 0)) {
+                const u32 tot = wave_scan_add(mine);
+                if (lane == KH_WAVE - 1) atomicAdd(&scratch[2], tot);
+            }
+        }
+        __syncthreads();
+        const u32 R = (scratch[2] + SKM_PH_ROUND - 1u) / SKM_PH_ROUND;
+        for (u32 q = 0; q < R; ++q) {
+            {   // a fresh table (the read-out before it is behind a barrier)
+                uint4* k4 = reinterpret_cast<uint4*>(tkey);
+#pragma unroll
+                for (u32 e = 0; e < T / 2 / NT; ++e) k4[e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+                reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);
+                reinterpret_cast<uint4*>(tcnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
+                unsigned long long e0 = EMPTY;
+                asm volatile("" : "+v"(e0));
+                if (tid < T2) { okey[tid] = e0; omlo[tid] = 0u; ocnt[tid] = 0u; }
+                if (tid == 0) { scratch[0] = 0; scratch[1] = 0; }
+            }
+            __syncthreads();
+            for (u32 ph = 0; ph < jb.npieces; ++ph) {
+                const KhSkmPiece pc = jb.pieces[ph];
+                u32 nrec = ((ConstU32)(unsigned long long)pc.count)[slot];
+                if (!nrec) continue;   // uniform
+                if (nrec > NT) {
+                    if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                    nrec = NT;
+                }
+                const u64 roff = ((ConstU32)(unsigned long long)pc.off)[slot];
+                const uint4* __restrict__ rec = pc.rec + roff;
+                const u32* __restrict__ msk = pc.mask + roff;
+                // ---- number the chunks of the phase's records
+                const u32 nj = tid < nrec ? rec[tid].w >> 27 : 0u;
+                const u32 nch = (nj + (u32)E - 1u) / (u32)E;
+                {
+                    const u32 incl = wave_scan_add(nch);
+                    u32 wbase = 0;
+                    if (lane == KH_WAVE - 1 && incl) wbase = atomicAdd(&scratch[0], incl);
+                    wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
+                    const u32 cstart = wbase + incl - nch;
+                    if (cstart + nch <= SKM_PH_MAXCH) {
+#pragma unroll
+                        for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
+                            if (cc < nch) owner[cstart + cc] = (u16)((tid << SKM_OB) | cc);
+                    }
+                }
+                __syncthreads();
+                u32 C = scratch[0];
+                if (C > SKM_PH_MAXCH) {
+                    if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                    C = 0;
+                }
+                unsigned long long emptyv = EMPTY;
+                asm volatile("" : "+v"(emptyv));
+                u32 fresh_n = 0;   // entries this thread created in this phase
+                for (u32 c = tid; c < C; c += NT) {
+                    const u32 o = owner[c], ri = o >> SKM_OB, first = (o & ((1u << SKM_OB) - 1u)) * (u32)E;
+                    const uint4 r0 = rec[ri];
+                    const u32 bits = msk[ri];
+                    const u32 left = (r0.w >> 27) - first;
+                    const u32 cnt = left < (u32)E ? left : (u32)E;
+                    const u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
+                    const u32 sh = 2u * first;
+                    const u64 lo = sh ? (clo >> sh) | (chi << (64u - sh)) : clo, hi = chi >> sh;
+                    const u32 xl = (u32)lo, xh = (u32)(lo >> 32) & kmh;
+                    const u64 fw = kh_revpairs64(((u64)xh << 32) | xl) >> fsh;
+                    u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl, rh = ~xh & kmh;
+                    const u32 t = (u32)((lo >> tsh) | (hi << (64u - tsh)));
+                    const u32 tc = ~t;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if (e) {
+                            fh = __builtin_amdgcn_alignbit(fh, fl, 30) & kmh;
+                            fl = (fl << 2) | ((t >> (2 * e)) & 3u);
+                            rl = __builtin_amdgcn_alignbit(rh, rl, 2);
+                            rh = (rh >> 2) | (((tc >> (2 * e)) & 3u) << tsh_hi);
+                        }
+                        if ((u32)e >= cnt) break;
+                        const bool fwd = fh < rh || (fh == rh && fl < rl);
+                        const u32 cl = fwd ? fl : rl, ch = fwd ? fh : rh;
+                        const unsigned long long K = ((u64)ch << 32) | cl;
+                        const u32 H = key_hash2(cl, ch);
+                        if (R != 1 && (((H >> 4) & 0xffffu) * R) >> 16 != q) continue;   // another round's key
+                        // main table: KH_TUNE_SKM_FULL_ROUNDS probes, then the second table (8), then the main one to the end
+                        u32 S = H >> (32 - HBITS), probes = 0, level = 0;
+                        while (true) {
+                            unsigned long long* kp = level == 1 ? okey : tkey;
+                            const unsigned long long o2 = atomicCAS(&kp[S], emptyv, K);
+                            if (o2 == emptyv || o2 == K) {
+                                atomicOr((level == 1 ? omlo : tmlo) + S, bits);
+                                if (o2 == emptyv) ++fresh_n;
+                                break;
+                            }
+                            ++probes;
+                            if (level == 0 && probes >= (u32)KH_TUNE_SKM_FULL_ROUNDS) {
+                                level = 1; probes = 0;
+                                S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> (32 - HBITS + 5);
+                            } else if (level == 1 && probes >= 8u) {
+                                level = 2; probes = 0;
+                                S = ((H >> (32 - HBITS)) + (u32)KH_TUNE_SKM_FULL_ROUNDS) & (T - 1u);
+                            } else if (level == 2 && probes >= T) {
+                                atomicOr(jb.ctl, KH_ERR_CAPACITY);   // the table is full
+                                break;
+                            } else {
+                                S = (S + 1u) & (level == 1 ? T2 - 1u : T - 1u);
+                            }
+                        }
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(fresh_n != 0)) {
+                    const u32 tot = wave_scan_add(fresh_n);
+                    if (lane == KH_WAVE - 1) atomicAdd(&scratch[1], tot);
+                }
+                __syncthreads();
+                // ---- fold: the phase's tags are counted, the mask plane is free for the next phase
+                {
+                    uint4 m4 = reinterpret_cast<uint4*>(tmlo)[tid];
+                    if (m4.x | m4.y | m4.z | m4.w) {
+                        uint4 c4 = reinterpret_cast<uint4*>(tcnt)[tid];
+                        c4.x += (u32)__popc(m4.x); c4.y += (u32)__popc(m4.y); c4.z += (u32)__popc(m4.z); c4.w += (u32)__popc(m4.w);
+                        reinterpret_cast<uint4*>(tcnt)[tid] = c4;
+                        reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                    if (tid < T2) { const u32 m = omlo[tid]; if (m) { ocnt[tid] += (u32)__popc(m); omlo[tid] = 0u; } }
+                    if (tid == 0) {
+                        scratch[0] = 0;
+                        if (scratch[1] > T - T / 16) atomicOr(jb.ctl, KH_ERR_CAPACITY);   // nearly full: probing would crawl
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- every occupied entry is one distinct k-mer of the slot; its counter: in how many (phase, tag) pairs
+            {
+                const uint4 c4 = reinterpret_cast<uint4*>(tcnt)[tid];
+                const u32 cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (cv[e]) {
+                        u32 c = cv[e] < jb.cs ? cv[e] : jb.cs;
+                        c = c < jb.hist_len - 1u ? c : jb.hist_len - 1u;
+                        if (c < hbins) atomicAdd(&lhist[c], 1u);
+                        else atomicAdd(&jb.hist[c], 1ull);
+                    }
+                }
+                if (tid < T2 && ocnt[tid]) {
+                    u32 c = ocnt[tid] < jb.cs ? ocnt[tid] : jb.cs;
+                    c = c < jb.hist_len - 1u ? c : jb.hist_len - 1u;
+                    if (c < hbins) atomicAdd(&lhist[c], 1u);
+                    else atomicAdd(&jb.hist[c], 1ull);
+                }
+                if (tid == 0 && q + 1 == R) scratch[2] = 0;   // (everybody has worked R out, barriers ago)
+            }
+            __syncthreads();
+        }
+        if (!R) __syncthreads();   // (an empty slot: scratch[2] is read again only behind the next barrier anyway)
+    }
+    __syncthreads();
+    if (tid0 < hbins && lhist[tid0]) atomicAdd(&jb.hist[tid0], (unsigned long long)lhist[tid0]);
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 template <class K> static void skm_allow_lds(K kern, size_t bytes) {
@@ -838,4 +1131,16 @@ void kh_launch_skm_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st) 
         skm_allow_lds(k_skm_union<1024, 4096>, lds);
         hipLaunchKernelGGL((k_skm_union<1024, 4096>), dim3(grid), dim3(1024), lds, st, job, cs);
     }
+}
+void kh_launch_skm_pack(const KhSkmPackJob& job, hipStream_t st) {
+    if (!job.nslots) return;
+    const size_t lds = kh_skm_pack_lds_bytes();
+    skm_allow_lds(k_skm_pack, lds);
+    hipLaunchKernelGGL(k_skm_pack, dim3(job.nslots), dim3(SKM_PK_NT), lds, st, job);
+}
+void kh_launch_skm_phased(const KhSkmPhasedJob& job, u32 grid, hipStream_t st) {
+    if (!job.nslots || !grid) return;
+    const size_t lds = kh_skm_phased_lds_bytes();
+    skm_allow_lds(k_skm_phased, lds);
+    hipLaunchKernelGGL(k_skm_phased, dim3(grid), dim3(SKM_PH_NT), lds, st, job);
 }

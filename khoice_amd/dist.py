@@ -334,6 +334,73 @@ def across_groups_auto(ops, group_sets: Sequence, k: int, cs: int, hist_len: int
     return across_groups_distributed(ops, group_sets, k, cs, hist_len, group)
 
 
+def across_records_exchange(ops, eng, seqs, group_of: Sequence[int], k: int, cs: int, hist_len: int, group=None) -> np.ndarray:
+    """Global step_8 histogram by exchange of MINIMIZER RECORDS (SURVEY.md §8e.2 in the super-k-mer form): slots are a
+    global function of the minimizer, so rank j owns a range of slots.  Every rank packs its genomes' records (tag =
+    local group, identical records merged) by owner, the packed arrays travel in four all-to-alls (records, masks, and
+    per slot how many / where), the owner runs one phased union over the pieces — a piece is a phase, tags of
+    different phases are different groups — and the small histogram is all-reduced.  0.5 GB of records per 250 Mbp and
+    rank instead of 0.93 GB of keys, and no rank builds a key set.  Collective: every rank must call it."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = ops.device
+    cdev = getattr(ops, "comm_device", dev)
+    to_comm = getattr(ops, "to_comm", lambda t: t)
+    from_comm = getattr(ops, "from_comm", lambda t: t)
+    trace = _Trace("records")
+    lens = [int(s[1]) if isinstance(s, tuple) else len(s) for s in seqs]
+    positions = sum(max(0, n - k + 1) for n in lens)
+    sizes = np.bincount(np.asarray(group_of, dtype=np.int64))
+    agree = torch.tensor([positions, int(sizes.max()) if sizes.size else 1], dtype=torch.int64, device=cdev)
+    dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=group)
+    nslots, spp, cap = eng.skm_exchange_plan(k, int(agree[0]), int(agree[1]), world)
+    rec = torch.empty((world, cap, 2), dtype=torch.int64, device=dev)
+    msk = torch.empty((world, cap), dtype=torch.int32, device=dev)
+    cnt = torch.empty((world, spp), dtype=torch.int32, device=dev)
+    off = torch.empty((world, spp), dtype=torch.int32, device=dev)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    part_n = eng.skm_pack(seqs, group_of, k, nslots, world, cap, rec.data_ptr(), msk.data_ptr(), cnt.data_ptr(), off.data_ptr())
+    trace("pack")
+    send_n = part_n.astype(np.int64)
+    send_n[rank] = 0                                  # the own part is used in place
+    sl = torch.from_numpy(send_n.copy()).to(cdev)
+    rl = torch.empty(world, dtype=torch.int64, device=cdev)
+    dist.all_to_all_single(rl, sl, group=group)
+    recv_n = rl.cpu().numpy()
+    # contiguous send buffers: the parts' used prefixes, destination-major
+    srec = torch.cat([rec[j, :int(send_n[j])].reshape(-1) for j in range(world)])
+    smsk = torch.cat([msk[j, :int(send_n[j])] for j in range(world)])
+    rrec = torch.empty(int(recv_n.sum()) * 2, dtype=torch.int64, device=cdev)
+    rmsk = torch.empty(int(recv_n.sum()), dtype=torch.int32, device=cdev)
+    dist.all_to_all_single(rrec, to_comm(srec), output_split_sizes=[int(n) * 2 for n in recv_n],
+                           input_split_sizes=[int(n) * 2 for n in send_n], group=group)
+    dist.all_to_all_single(rmsk, to_comm(smsk), output_split_sizes=[int(n) for n in recv_n],
+                           input_split_sizes=[int(n) for n in send_n], group=group)
+    rcnt = torch.empty((world, spp), dtype=torch.int32, device=cdev)
+    roff = torch.empty((world, spp), dtype=torch.int32, device=cdev)
+    dist.all_to_all_single(rcnt.view(-1), to_comm(cnt.view(-1)), group=group)
+    dist.all_to_all_single(roff.view(-1), to_comm(off.view(-1)), group=group)
+    rrec, rmsk, rcnt, roff = from_comm(rrec), from_comm(rmsk), from_comm(rcnt), from_comm(roff)
+    ops.before_wrap()
+    trace("all_to_all")
+    pieces, at = [], 0
+    for i in range(world):
+        if i == rank:
+            pieces.append((rec[rank].data_ptr(), msk[rank].data_ptr(), cnt[rank].data_ptr(), off[rank].data_ptr()))
+        else:
+            pieces.append((rrec.data_ptr() + 16 * at, rmsk.data_ptr() + 4 * at, rcnt[i].data_ptr(), roff[i].data_ptr()))
+        at += int(recv_n[i])
+    hist = eng.skm_phased_histogram(k, pieces, spp, cs, hist_len)
+    trace("union")
+    ht = torch.from_numpy(hist.astype(np.int64)).to(cdev)
+    dist.all_reduce(ht, op=dist.ReduceOp.SUM, group=group)
+    out = ht.cpu().numpy().astype(np.uint64)
+    trace("all_reduce")
+    trace.report()
+    return out
+
+
 def exp1_step(eng, seqs, group_of: Sequence[int], k: int, cs: int = 5000, hist_len: int = 5001,
               group=None):
     """One benchmark step on N GPUs: steps 1-6 locally, steps 7-8 through the exchange.
@@ -345,6 +412,14 @@ def exp1_step(eng, seqs, group_of: Sequence[int], k: int, cs: int = 5000, hist_l
         gsets = [s.set_counts(1) for s in res["group_sets"]]
         res["across_hist"] = across_groups_auto(ops, gsets, k, cs, hist_len, group)
         del res["group_sets"]
+        return res
+    import os
+    lo, hi = eng.SKM_EXCHANGE_K
+    if lo <= k <= hi and max(group_of) < 32 and not os.environ.get("KHOICE_DIST_SET_EXCHANGE"):
+        # the super-k-mer form on every rank: steps 1-6 locally (no set is built), steps 7-8 by exchange of records
+        res = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len, across=False)
+        res["across_hist"] = across_records_exchange(ops, eng, seqs, group_of, k, cs, hist_len, group)
+        res["exchange"] = "records"
         return res
     # the fused local step, emitting only this rank's across-group set (counter = local groups)
     res = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len, across=False, want_across_set=True)

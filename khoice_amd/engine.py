@@ -101,6 +101,11 @@ def load_library(path: Optional[str] = None):
         "kh_across_exchange_histogram": (C.c_int, [vp, vp, vp, C.c_uint32, u64p, C.c_uint32]),
         "kh_mix_host": (None, [C.c_int, u64p, u64p]),
         "kh_unmix_host": (None, [C.c_int, u64p, u64p]),
+        "kh_skm_exchange_plan": (C.c_int, [vp, C.c_int, C.c_uint64, C.c_uint32, C.c_int, u32p, u32p, u64p]),
+        "kh_skm_pack": (C.c_int, [vp, C.c_int, C.POINTER(vp), u64p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_uint32,
+                                  C.c_int, C.c_uint64, vp, vp, vp, vp, u64p]),
+        "kh_skm_phased_histogram": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                              C.POINTER(vp), C.c_uint32, C.c_uint32, u64p, C.c_uint32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
@@ -123,6 +128,7 @@ ABI_SYMBOLS = [
     "kh_set_export_range", "kh_set_wrap_device", "kh_set_partition_bounds",
     "kh_sets_partition_bounds",
     "kh_save", "kh_load", "kh_exp1_run", "kh_comm_unique_id", "kh_comm_init", "kh_comm_destroy",
+    "kh_skm_exchange_plan", "kh_skm_pack", "kh_skm_phased_histogram",
     "kh_across_exchange_histogram", "kh_mix_host", "kh_unmix_host",
 ]
 
@@ -541,6 +547,38 @@ class Engine:
         if (want_sets and do_across) or want_across_set:
             res["across_set"] = KmerSet(self, aset.value)
         return res
+
+    # -- steps 7-8 across ranks by exchange of minimizer records (khoice_amd/dist.py; 20 <= k <= 32)
+    SKM_EXCHANGE_K = (20, 32)
+
+    def skm_exchange_plan(self, k: int, positions_max: int, fan_max: int, nparts: int):
+        """(nslots, slots_per_part, part_cap): the slot geometry every rank must use, from numbers the ranks agreed on."""
+        ns, spp, cap = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        _check(self._lib.kh_skm_exchange_plan(self._ctx, k, positions_max, fan_max, nparts, C.byref(ns), C.byref(spp),
+                                              C.byref(cap)))
+        return ns.value, spp.value, cap.value
+
+    def skm_pack(self, seqs: Sequence, tag_of: Sequence[int], k: int, nslots: int, nparts: int, part_cap: int,
+                 rec_ptr: int, mask_ptr: int, count_ptr: int, off_ptr: int) -> np.ndarray:
+        """This rank's genomes -> records tagged with tag_of[i] (local group, 0..31), identical ones merged, packed by
+        owner of their slot into the caller's device buffers.  Returns the number of records per part."""
+        ptrs, lens, on_dev, keep = self._seq_args(seqs)
+        n = len(seqs)
+        tags = (C.c_int * n)(*[int(t) for t in tag_of])
+        part_n = np.zeros(nparts, dtype=np.uint64)
+        _check(self._lib.kh_skm_pack(self._ctx, n, ptrs, _u64p(lens), on_dev, tags, k, nslots, nparts, part_cap,
+                                     rec_ptr, mask_ptr, count_ptr, off_ptr, _u64p(part_n)))
+        return part_n
+
+    def skm_phased_histogram(self, k: int, pieces: Sequence, nslots: int, cs: int, hist_len: int) -> np.ndarray:
+        """pieces: (rec_ptr, mask_ptr, count_ptr, off_ptr) per source rank, device pointers.  hist[c] = distinct k-mers of
+        this rank's slots that occur in c (source, tag) pairs."""
+        n = len(pieces)
+        arrs = [(C.c_void_p * n)(*[int(pc[j]) for pc in pieces]) for j in range(4)]
+        hist = np.zeros(hist_len, dtype=np.uint64)
+        _check(self._lib.kh_skm_phased_histogram(self._ctx, k, n, arrs[0], arrs[1], arrs[2], arrs[3], nslots, cs,
+                                                 _u64p(hist), hist_len))
+        return hist
 
 
 def mix_host(k: int, key_words: np.ndarray) -> np.ndarray:

@@ -9,10 +9,13 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_two_ranks_share_one_gpu():
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_ranks_share_one_gpu(ranks):
+    """The exchange of minimizer records and of key sets, 2 and 3 ranks, against the single-process engine and
+    the C restatement (tests/dist_rehearsal.py)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29571",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29571 + ranks),
                         os.path.join(HERE, "dist_rehearsal.py")],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "REHEARSAL_OK" in r.stdout, r.stdout[-3000:]
