@@ -231,3 +231,125 @@ def test_small_k_table_all_reduce_matches_slot_exchange_and_oracle(layout, k):
     for _, ht, hs, ha in got:
         assert ht == want and hs == want and ha == want
     assert sum(want[2:]) > 0
+
+
+class RecordStandIn:
+    """Oracle-backed stand-in for the three engine calls of the RECORDS exchange (khoice_amd.dist.across_records_exchange):
+    a "record" is one canonical k-mer (its code in the first word), its mask the local groups that hold it; slots are a
+    hash of the k-mer.  What is under test is the Python side: the agreed geometry, the packed parts, the four all-to-alls
+    with their split sizes, the per-slot counts / offsets, the pieces handed to the owner."""
+    SKM_EXCHANGE_K = (20, 32)
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.nslots = rank, world, None
+
+    @staticmethod
+    def _view(ptr, n, dtype):
+        import ctypes
+        if n == 0:
+            return np.zeros(0, dtype=dtype)
+        return np.frombuffer((ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype)
+
+    def skm_exchange_plan(self, k, positions_max, fan_max, nparts):
+        nslots = max(nparts, positions_max // 50 + 7)
+        spp = (nslots + nparts - 1) // nparts
+        self.plan = (nslots, spp, positions_max + 64)
+        return self.plan
+
+    def slot_of(self, codes, nslots):
+        x = (codes * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(20)
+        return (x % np.uint64(nslots)).astype(np.int64)
+
+    def skm_pack(self, seqs, tag_of, k, nslots, nparts, part_cap, rec_ptr, mask_ptr, count_ptr, off_ptr):
+        assert (nslots, (nslots + nparts - 1) // nparts, part_cap) == self.plan
+        spp = self.plan[1]
+        masks = {}
+        for s, t in zip(seqs, tag_of):
+            for code in O.count_records(s.decode().split("\n"), k):
+                masks[code] = masks.get(code, 0) | (1 << t)
+        codes = np.array(sorted(masks), dtype=np.uint64)
+        slot = self.slot_of(codes, nslots)
+        order = np.lexsort((codes, slot))
+        codes, slot = codes[order], slot[order]
+        rec = self._view(rec_ptr, nparts * part_cap * 2, np.int64).reshape(nparts, part_cap, 2)
+        msk = self._view(mask_ptr, nparts * part_cap, np.int32).reshape(nparts, part_cap)
+        cnt = self._view(count_ptr, nparts * spp, np.int32).reshape(nparts, spp)
+        off = self._view(off_ptr, nparts * spp, np.int32).reshape(nparts, spp)
+        cnt[:] = 0
+        off[:] = 0
+        part_n = np.zeros(nparts, dtype=np.uint64)
+        for p in range(nparts):
+            sel = (slot // spp) == p
+            n = int(sel.sum())
+            part_n[p] = n
+            rec[p, :n, 0] = codes[sel].view(np.int64)
+            rec[p, :n, 1] = 0x5A5A
+            msk[p, :n] = np.array([masks[int(c)] for c in codes[sel]], dtype=np.int64).astype(np.int32)
+            local = slot[sel] - p * spp
+            cnt[p] = np.bincount(local, minlength=spp)[:spp]
+            off[p] = np.concatenate([[0], np.cumsum(cnt[p])[:-1]])
+        return part_n
+
+    def skm_phased_histogram(self, k, pieces, nslots, cs, hist_len):
+        nslots_all, spp, _ = self.plan
+        assert nslots == spp and len(pieces) == self.world
+        tags = {}
+        for rp, mp_, cp, op in pieces:
+            cnt = self._view(cp, spp, np.int32)
+            off = self._view(op, spp, np.int32)
+            total = int(cnt.sum())
+            assert total == 0 or int((off + cnt).max()) == total
+            rec = self._view(rp, total * 2, np.int64).reshape(total, 2)
+            msk = self._view(mp_, total, np.int32)
+            assert (rec[:, 1] == 0x5A5A).all()
+            codes = rec[:, 0].view(np.uint64)
+            assert (self.slot_of(codes, nslots_all) // spp == self.rank).all()        # only this owner's slots arrive
+            for s in range(spp):                                                    # and the per-slot tables are right
+                seg = codes[off[s]:off[s] + cnt[s]]
+                assert (self.slot_of(seg, nslots_all) == self.rank * spp + s).all()
+            for c, m in zip(codes.tolist(), msk.tolist()):
+                tags[c] = tags.get(c, 0) + bin(m & 0xffffffff).count("1")
+        h = np.zeros(hist_len, dtype=np.uint64)
+        for n in tags.values():
+            h[min(n, cs, hist_len - 1)] += 1
+        return h
+
+
+def records_worker(rank, world, port, groups_per_rank, q):
+    from khoice_amd import dist as kdist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        first = 1 + sum(groups_per_rank[:rank])
+        seqs, group_of = [], []
+        for g in range(groups_per_rank[rank]):
+            anc = synth.ancestor(first + g, 3000)
+            for j in range(2):
+                seqs.append(synth.clean_text(synth.genome_records(first + g, j, 3000, anc)))
+                group_of.append(g)
+        if not seqs:                       # a rank without groups still takes part in every collective
+            seqs, group_of = [b"ACGT"], [0]
+        ops = OracleOps(K, rank, world)
+        hist = kdist.across_records_exchange(ops, RecordStandIn(rank, world), seqs, group_of, K, 5000, 64)
+        q.put((rank, hist.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout", [[3, 3], [2, 0, 3]])
+def test_records_exchange_matches_single_process(layout):
+    """The exchange the benchmark takes at N > 1 for 20 <= k <= 32 (minimizer records by slot owner), on CPU."""
+    world = len(layout)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=records_worker, args=(r, world, port, layout, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = O.histogram(O.union_sum([group_db(1 + g, length=3000) for g in range(sum(layout))], 5000), 63)
+    for _, h in got:
+        assert h == want
+    assert sum(want[2:]) > 0
