@@ -271,12 +271,13 @@ extern "C" int kh_stats(kh_ctx* c, char* buf, size_t buflen) {
     s += t;
     snprintf(t, sizeof t,
              "\"builds\":%llu,\"bases\":%llu,\"kmers\":%llu,\"distinct\":%llu,\"setops\":%llu,"
-             "\"setop_in\":%llu,\"setop_out\":%llu,\"retries\":%llu,\"order_fallbacks\":%llu,\"skm_records\":%llu,\"pool_bytes\":%zu,",
+             "\"setop_in\":%llu,\"setop_out\":%llu,\"retries\":%llu,\"order_fallbacks\":%llu,\"skm_records\":%llu,\"big_slots\":%llu,\"pool_bytes\":%zu,",
              (unsigned long long)c->stat.builds, (unsigned long long)c->stat.bases,
              (unsigned long long)c->stat.kmers, (unsigned long long)c->stat.distinct,
              (unsigned long long)c->stat.setops, (unsigned long long)c->stat.setop_in,
              (unsigned long long)c->stat.setop_out, (unsigned long long)c->stat.retries,
-             (unsigned long long)c->stat.order_fallbacks, (unsigned long long)c->stat.skm_records, c->pool.total_bytes);
+             (unsigned long long)c->stat.order_fallbacks, (unsigned long long)c->stat.skm_records,
+             (unsigned long long)c->stat.big_slots, c->pool.total_bytes);
     s += t;
     s += "\"kernels\":{";
     for (int i = 0; i < KC_COUNT; ++i) {
@@ -1680,7 +1681,9 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
                  off_ginfo = off_cur2 + 4 * (size_t)((nslots + 3) & ~3u), off_tags = off_ginfo + 256,
                  off_segs = off_tags + (((size_t)nseq + 15) & ~(size_t)15), off_tiles = off_segs + sizeof(KhSeg) * nseq,
                  ws_bytes = off_tiles + sizeof(KhTile) * (size_t)std::max<u32>(1, ntiles);   // [ginfo .. tiles]: one upload
-    Tmp d_seq, d_ws, d_reg1, d_reg2;
+    Tmp d_seq, d_ws, d_reg1, d_reg2, d_spill;
+    // one-word keys: what a slot's region cannot hold goes to a side list, the slot to a kernel of its own
+    const u32 spill_cap = two ? 0u : 1u << 17, big_cap = two ? 0u : 4096u;
     bool need_pack = false;
     for (int i = 0; i < nseq; ++i)
         if (!(on_device && (reinterpret_cast<uintptr_t>(seqs[perm[i]]) & 15) == 0)) need_pack = true;
@@ -1688,6 +1691,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     TMP_ALLOC(d_ws, c, ws_bytes);
     TMP_ALLOC(d_reg1, c, reg1_bytes);
     TMP_ALLOC(d_reg2, c, reg2_bytes);
+    if (spill_cap) TMP_ALLOC(d_spill, c, (size_t)spill_cap * 20 + (size_t)big_cap * 4);
     struct PinG { kh_ctx* c; void* p = nullptr; size_t n = 0; ~PinG() { if (p) c->pin_release(p, n); } } pin{c};
     // pinned staging: [segs][tiles][ginfo] up, [hist .. dup] down
     const size_t up_bytes = ws_bytes - off_ginfo;   // the upload, laid out as on the device
@@ -1743,6 +1747,11 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     job.nslots = nslots; job.S = S; job.nb1 = nb1; job.cap1 = cap1; job.cap2 = cap2;
     job.nbins = nbins; job.abase = abase; job.reps = reps; job.nops = by_group ? (u32)ngroups : (u32)nseq;
     job.table = table;
+    job.spill_rec = spill_cap ? d_spill.as<uint4>() : nullptr;
+    job.spill_slot = spill_cap ? reinterpret_cast<u32*>(d_spill.as<u8>() + (size_t)spill_cap * 16) : nullptr;
+    job.big_list = spill_cap ? reinterpret_cast<u32*>(d_spill.as<u8>() + (size_t)spill_cap * 20) : nullptr;
+    job.spill_cap = spill_cap;
+    job.big_cap = big_cap;
 #ifdef KH_STAMPS
     Tmp d_stamps;
     const u64 nst = std::max<u64>(ntiles, nslots);
@@ -1768,10 +1777,11 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
 #endif
     if (rec_out) {   // the records by slot are what the caller wants
         HIPCHK(hipGetLastError());
-        u32 h_ctl[4] = {0, 0, 0, 0};
-        HIPCHK(hipMemcpyAsync(h_ctl, job.ctl, 16, hipMemcpyDeviceToHost, st));
+        u32 h_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(h_ctl, job.ctl, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER)) { c->stat.retries++; return KH_OK; }
+        // (records on the side list are not part of what is handed out: an overfull slot is a failure here)
+        if ((h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER)) || h_ctl[5]) { c->stat.retries++; return KH_OK; }
         c->stat.skm_records += h_ctl[2];
         rec_out->records = h_ctl[2];
         rec_out->reg2 = d_reg2.b; d_reg2.b = nullptr;
@@ -1811,6 +1821,18 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     HIPCHK(hipStreamSynchronize(st));
     const u64* h_hist = reinterpret_cast<const u64*>(h_down);
     const u32* h_ctl = reinterpret_cast<const u32*>(h_down + off_ctl);
+    if (!two && h_ctl[6] && !(h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER))) {
+        // overfull slots (skewed input: a minimizer shared by far more k-mers than a hash predicts): the union left
+        // them out; one workgroup each now, and the read-back again — only these slots are done twice, not the call
+        if (h_ctl[5] > spill_cap || h_ctl[6] > big_cap) { c->stat.retries++; return KH_OK; }   // too many: the key-array form
+        c->stat.big_slots += h_ctl[6];
+        c->prof_begin(KC_SKM_UNION);
+        kh_launch_skm_big(job, cs, h_ctl[6], st);
+        c->prof_end();
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_down, wsp, down_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
     const u64* h_inst = reinterpret_cast<const u64*>(h_down + off_inst);
     const u64* h_dup = reinterpret_cast<const u64*>(h_down + off_dup);
     if (h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER)) {

@@ -36,7 +36,7 @@ enum KernelClass {
 struct ProfEvt { int cls; hipEvent_t a, b; };
 struct Stats {
     u64 builds = 0, bases = 0, kmers = 0, distinct = 0, setops = 0, setop_in = 0, setop_out = 0,
-        retries = 0, order_fallbacks = 0, skm_records = 0;
+        retries = 0, order_fallbacks = 0, skm_records = 0, big_slots = 0;
 };
 
 struct kh_ctx {

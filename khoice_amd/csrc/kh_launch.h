@@ -155,6 +155,11 @@ struct KhSkmJob {
     u32 nslots, S, nb1, cap1, cap2;
     u32 nbins, abase, reps, nops;
     u32 table;                      // entries of the union's hash set: 4096 (1024 threads) or 2048 (512 threads); one-word keys
+    // one-word keys: records of slots whose region is full (regroup) and the slots the union leaves to k_skm_big
+    uint4* spill_rec;               // [spill_cap]; nullptr: a full region is an error (two-word keys)
+    u32* spill_slot;                // [spill_cap]
+    u32* big_list;                  // [big_cap] slots with more records than their region holds
+    u32 spill_cap, big_cap;         // counters: ctl[5] records spilled, ctl[6] slots listed
 };
 bool kh_skm_supports_w(u32 w);   // m-mers per k-mer the scatter kernel is instantiated for
 size_t kh_skm_scatter_lds_bytes(u32 nb1);
@@ -165,6 +170,7 @@ void kh_launch_skm_scatter(const KhSkmJob& job, u32 ntiles, hipStream_t st);
 void kh_launch_skm_regroup(const KhSkmJob& job, hipStream_t st);
 void kh_launch_skm_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st);   // persistent: grid workgroups walk the slots
 u32 kh_skm_union_per_cu(u32 table);   // workgroups of the union that fit a CU
+void kh_launch_skm_big(const KhSkmJob& job, u32 cs, u32 nbig, hipStream_t st);   // the slots of big_list, one workgroup each
 // ---- the exchange form of the across-group step (multi-GPU; kh_skm.hip k_skm_pack / k_skm_phased)
 struct KhSkmPackJob {
     const uint4* reg2;              // [nslots][cap2] this rank's records by slot (tag = local group, < 32)

@@ -336,7 +336,9 @@ __global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm_regroup(const KhSkmJob jb)
             nx[r] = i < cnt ? src[i] : make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
-        skm_flush<SKM_RG_NT, SKM_RG_CAP, true>(L, n, nfine, lcur, dst, jb.cap2, jb.ctl);
+        SkmSpill sp;
+        sp.rec = jb.spill_rec; sp.slot = jb.spill_slot; sp.n = jb.ctl + 5; sp.cap = jb.spill_cap; sp.first_slot = first_slot;
+        skm_flush<SKM_RG_NT, SKM_RG_CAP, true>(L, n, nfine, lcur, dst, jb.cap2, jb.ctl, sp);
     }
     for (u32 i = tid; i < nfine; i += SKM_RG_NT) jb.cur2[first_slot + i] = lcur[i];
 }
@@ -455,10 +457,12 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
     // space, i.e. by SCALAR loads (inside the slot loop the compiler cannot prove that for a plain global pointer)
     typedef const u32 __attribute__((address_space(4))) * ConstU32;
     const ConstU32 counts = (ConstU32)(unsigned long long)jb.cur2;
+    // (a slot with more records than its region holds — the rest were spilled by the regroup — is not this kernel's:
+    // it is listed for k_skm_big and counts as empty here)
+    const u32 fit = cap2 < G::MAXREC ? cap2 : G::MAXREC;
     auto count_of = [&](u32 sl) -> u32 {
-        u32 n = sl < nslots ? counts[sl] : 0u;
-        n = n < cap2 ? n : cap2;
-        return n < G::MAXREC ? n : G::MAXREC;
+        const u32 n = sl < nslots ? counts[sl] : 0u;
+        return n <= fit ? n : 0u;
     };
     SKM_MARK("init");
     if (tid < (u32)KH_TAG_MAX_OPS) {
@@ -508,6 +512,12 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
         lane = tid & (KH_WAVE - 1u);
         const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2;
         const u32 nrec_after = count_of(slot + 2u * stride);   // (a scalar load: two slots ahead)
+        if (!nrec && counts[slot] > fit) {   // uniform: an overfull slot
+            if (tid0 == 0) {
+                const u32 at = atomicAdd(jb.ctl + 6, 1u);
+                if (at < jb.big_cap) jb.big_list[at] = slot;
+            }
+        }
         // ---- stage this slot's records, one per thread
         u32 nj = 0;   // k-mers of this thread's record while it is alive
         const u32 tg = (rr.w >> 21) & 63u;
@@ -800,6 +810,212 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
         if (st_full > T) atomicMax(jb.ctl + 1, st_full);
         atomicAdd(jb.ctl + 3, st_exp);   // k-mer instances that were expanded
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Overfull slots (one-word keys).  A minimizer that far more k-mers share than a hash predicts — poly-A, a tandem repeat's
+// unit, an insertion sequence in 50 copies — fills its slot's region; the regroup puts what does not fit on a side
+// list and the union leaves such slots alone.  Here one workgroup takes one of them whatever its size: the records
+// in the region, then its records on the side list (found by a scan of the list: it is short), every k-mer into the
+// table in rounds of key subsets; no merge of identical records, read-out by a scan of the table.  A handful of
+// slots per run: nothing here is tuned, it only has to be right and to keep the run in the fast form.
+// ------------------------------------------------------------------------------------------
+constexpr u32 SKM_BIG_NT = 1024, SKM_BIG_T = 4096, SKM_BIG_T2 = 128, SKM_BIG_IDX = 4096;
+constexpr u32 SKM_BIG_BATCH = 256, SKM_BIG_MAXCH = SKM_BIG_BATCH << SKM_OB;   // records numbered at a time; their chunks at most
+size_t kh_skm_big_lds_bytes() {
+    return (size_t)SKM_BIG_T * 16 + (size_t)SKM_BIG_T2 * 16 + 1024 + 128 + 256 + (size_t)SKM_HSTRIPE_WORDS * 4 +
+           (size_t)SKM_BIG_MAXCH * 2 + (size_t)SKM_BIG_IDX * 4;
+}
+__global__ __launch_bounds__(SKM_BIG_NT) void k_skm_big(const KhSkmJob jb, u32 cs) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    constexpr u32 NT = SKM_BIG_NT, T = SKM_BIG_T, T2 = SKM_BIG_T2, HBITS = 12;
+    constexpr int E = (int)SKM_UE;
+    constexpr u64 EMPTY = ~0ull;
+    u8* p = lds_raw;
+    unsigned long long* tkey = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T * 8;
+    u32* tmlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T * 4;
+    u32* tmhi = reinterpret_cast<u32*>(p);                                 p += (size_t)T * 4;
+    unsigned long long* okey = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T2 * 8;
+    u32* omlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
+    u32* omhi = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
+    uint4* gtab = reinterpret_cast<uint4*>(p);                             p += 1024;
+    u32* scratch = reinterpret_cast<u32*>(p);                              p += 128;   // [0] chunks, [2] k-mers, [3] side-list records
+    u32* dupc = reinterpret_cast<u32*>(p);                                 p += 256;
+    u32* hstripe = reinterpret_cast<u32*>(p);                              p += (size_t)SKM_HSTRIPE_WORDS * 4;
+    u16* owner = reinterpret_cast<u16*>(p);                                p += (size_t)SKM_BIG_MAXCH * 2;
+    u32* sidx = reinterpret_cast<u32*>(p);                                 // [SKM_BIG_IDX] this slot's records on the side list
+    const u32 tid = threadIdx.x, lane = lane_id();
+    const u32 nbins = jb.nbins, cap2 = jb.cap2;
+    const int k = jb.k;
+    const u32 slot = jb.big_list[blockIdx.x];
+    const u32 sshift = nbins <= 72u ? 2u : (nbins <= 144u ? 1u : 0u), smask = (1u << sshift) - 1u;
+    const u32 kmh = (u32)(kh_mask(2 * k) >> 32), fsh = 64u - 2u * (u32)k, tsh = 2u * (u32)k - 2u, tsh_hi = tsh - 32u;
+    if (tid < (u32)KH_TAG_MAX_OPS) {
+        const u32 g = jb.ginfo[tid], g0 = g & 0xffu, gn = (g >> 8) & 0xffu;
+        const u64 gm = gn ? (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0 : 0ull;
+        gtab[tid] = make_uint4((u32)gm, (u32)(gm >> 32), (g >> 16) << sshift, 0u);
+        dupc[tid] = 0;
+    }
+    if (tid < SKM_HSTRIPE_WORDS) hstripe[tid] = 0;
+    if (tid < 8) scratch[tid] = 0;
+    __syncthreads();
+    // ---- this slot's records on the side list
+    u32 nspill_all = jb.ctl[5];
+    nspill_all = nspill_all < jb.spill_cap ? nspill_all : jb.spill_cap;
+    for (u32 i = tid; i < nspill_all; i += NT) {
+        if (jb.spill_slot[i] == slot) {
+            const u32 at = atomicAdd(&scratch[3], 1u);
+            if (at < SKM_BIG_IDX) sidx[at] = i;
+        }
+    }
+    __syncthreads();
+    u32 nside = scratch[3];
+    if (nside > SKM_BIG_IDX) {   // (more than this kernel indexes: the host falls back)
+        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+        nside = SKM_BIG_IDX;
+    }
+    const u32 nreg = cap2;   // (the region of an overfull slot is full)
+    const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2;
+    const u32 nall = nreg + nside;
+    auto record = [&](u32 i) -> uint4 { return i < nreg ? reg[i] : jb.spill_rec[sidx[i - nreg]]; };
+    // ---- k-mer instances of the slot -> rounds
+    {
+        u32 mine = 0;
+        for (u32 i = tid; i < nall; i += NT) mine += record(i).w >> 27;
+        const u32 tot = wave_scan_add(mine);
+        if (lane == KH_WAVE - 1 && tot) atomicAdd(&scratch[2], tot);
+    }
+    __syncthreads();
+    const u32 N = scratch[2];
+    const u32 R = (N + 3071u) / 3072u;
+    if (tid == 0 && N > T) atomicMax(jb.ctl + 1, N);
+    auto eval_mask = [&](u32 mlo, u32 mhi) -> bool {
+        const u32 lsel = lane & smask;
+        u32 ng = 0;
+        do {
+            const u32 first = mlo ? (u32)__builtin_ctz(mlo) : 32u + (u32)__builtin_ctz(mhi);
+            const uint4 g = gtab[first];
+            u32 c = (u32)__popc(mlo & g.x) + (u32)__popc(mhi & g.y);
+            c = c < cs ? c : cs;
+            atomicAdd(&hstripe[g.z + (c << sshift) + lsel], 1u);
+            const u32 keep_hi = mlo ? ~0u : mhi - 1u;
+            mlo &= ~g.x & (mlo - 1u);
+            mhi &= ~g.y & keep_hi;
+            ++ng;
+        } while (mlo | mhi);
+        if (ng == 1u) return true;
+        atomicAdd(&hstripe[((jb.abase + (ng < cs ? ng : cs)) << sshift) + lsel], 1u);
+        return false;
+    };
+    for (u32 q = 0; q < R; ++q) {
+        {
+            uint4* k4 = reinterpret_cast<uint4*>(tkey);
+#pragma unroll
+            for (u32 e = 0; e < T / 2 / NT; ++e) k4[e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint4*>(tmhi)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid < T2) { okey[tid] = EMPTY; omlo[tid] = 0u; omhi[tid] = 0u; }
+        }
+        __syncthreads();
+        for (u32 b0 = 0; b0 < nall; b0 += SKM_BIG_BATCH) {   // batches of records, one per thread of the first waves
+            const u32 mine_i = b0 + tid;
+            const u32 nj = tid < SKM_BIG_BATCH && mine_i < nall ? record(mine_i).w >> 27 : 0u;
+            const u32 nch = (nj + (u32)E - 1u) / (u32)E;
+            {
+                const u32 incl = wave_scan_add(nch);
+                u32 wbase = 0;
+                if (lane == KH_WAVE - 1 && incl) wbase = atomicAdd(&scratch[0], incl);
+                wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
+                const u32 cstart = wbase + incl - nch;
+                if (cstart + nch <= SKM_BIG_MAXCH) {
+#pragma unroll
+                    for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
+                        if (cc < nch) owner[cstart + cc] = (u16)((tid << SKM_OB) | cc);
+                }
+            }
+            __syncthreads();
+            u32 C = scratch[0];
+            if (C > SKM_BIG_MAXCH) {   // (cannot happen: a record has at most 1 << SKM_OB chunks)
+                if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                C = 0;
+            }
+            for (u32 c = tid; c < C; c += NT) {
+                const u32 o = owner[c], ri = b0 + (o >> SKM_OB), first = (o & ((1u << SKM_OB) - 1u)) * (u32)E;
+                const uint4 r0 = record(ri);
+                const u32 tg = (r0.w >> 21) & 63u, bit = 1u << (tg & 31u), half = tg >> 5;
+                const u32 left = (r0.w >> 27) - first;
+                const u32 cnt = left < (u32)E ? left : (u32)E;
+                const u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
+                const u32 sh = 2u * first;
+                const u64 lo = sh ? (clo >> sh) | (chi << (64u - sh)) : clo, hi = chi >> sh;
+                const u32 xl = (u32)lo, xh = (u32)(lo >> 32) & kmh;
+                const u64 fw = kh_revpairs64(((u64)xh << 32) | xl) >> fsh;
+                u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl, rh = ~xh & kmh;
+                const u32 t = (u32)((lo >> tsh) | (hi << (64u - tsh)));
+                const u32 tc = ~t;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (e) {
+                        fh = __builtin_amdgcn_alignbit(fh, fl, 30) & kmh;
+                        fl = (fl << 2) | ((t >> (2 * e)) & 3u);
+                        rl = __builtin_amdgcn_alignbit(rh, rl, 2);
+                        rh = (rh >> 2) | (((tc >> (2 * e)) & 3u) << tsh_hi);
+                    }
+                    if ((u32)e >= cnt) break;
+                    const bool fwd = fh < rh || (fh == rh && fl < rl);
+                    const u32 cl = fwd ? fl : rl, ch = fwd ? fh : rh;
+                    const unsigned long long K = ((u64)ch << 32) | cl;
+                    const u32 H = key_hash2(cl, ch);
+                    if (R != 1 && (((H >> 4) & 0xffffu) * R) >> 16 != q) continue;
+                    u32 S = H >> (32 - HBITS), probes = 0, level = 0;
+                    while (true) {
+                        unsigned long long* kp = level == 1 ? okey : tkey;
+                        const unsigned long long o2 = atomicCAS(&kp[S], EMPTY, K);
+                        if (o2 == EMPTY || o2 == K) {
+                            u32* mp = level == 1 ? (half ? omhi : omlo) : (half ? tmhi : tmlo);
+                            if (atomicOr(mp + S, bit) & bit) atomicAdd(&dupc[tg], 1u);   // this genome had the k-mer already
+                            break;
+                        }
+                        ++probes;
+                        if (level == 0 && probes >= (u32)KH_TUNE_SKM_FULL_ROUNDS) {
+                            level = 1; probes = 0;
+                            S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> (32 - HBITS + 5);
+                        } else if (level == 1 && probes >= 8u) {
+                            level = 2; probes = 0;
+                            S = ((H >> (32 - HBITS)) + (u32)KH_TUNE_SKM_FULL_ROUNDS) & (T - 1u);
+                        } else if (level == 2 && probes >= T) {
+                            atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                            break;
+                        } else {
+                            S = (S + 1u) & (level == 1 ? T2 - 1u : T - 1u);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) scratch[0] = 0;
+            __syncthreads();
+        }
+        // ---- read-out: every occupied entry
+        u32 ones = 0;
+#pragma unroll
+        for (u32 e = 0; e < T / NT; ++e) {
+            const u32 i = e * NT + tid;
+            if (tkey[i] != EMPTY && eval_mask(tmlo[i], tmhi[i])) ++ones;
+        }
+        if (tid < T2 && okey[tid] != EMPTY && eval_mask(omlo[tid], omhi[tid])) ++ones;
+        ones = wave_scan_add(ones);
+        if (lane == KH_WAVE - 1 && ones) atomicAdd(&hstripe[(jb.abase + 1u) << sshift], ones);
+        __syncthreads();
+    }
+    unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
+    for (u32 i = tid; i < nbins; i += NT) {
+        u32 v = 0;
+        for (u32 j = 0; j <= smask; ++j) v += hstripe[(i << sshift) + j];
+        if (v) atomicAdd(&rep[i], (unsigned long long)v);
+    }
+    if (tid < (u32)KH_TAG_MAX_OPS && dupc[tid]) atomicAdd(&jb.dup[tid], (unsigned long long)dupc[tid]);
+    if (tid == 0) atomicAdd(jb.ctl + 3, N);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1143,4 +1359,10 @@ void kh_launch_skm_phased(const KhSkmPhasedJob& job, u32 grid, hipStream_t st) {
     const size_t lds = kh_skm_phased_lds_bytes();
     skm_allow_lds(k_skm_phased, lds);
     hipLaunchKernelGGL(k_skm_phased, dim3(grid), dim3(SKM_PH_NT), lds, st, job);
+}
+void kh_launch_skm_big(const KhSkmJob& job, u32 cs, u32 nbig, hipStream_t st) {
+    if (!nbig) return;
+    const size_t lds = kh_skm_big_lds_bytes();
+    skm_allow_lds(k_skm_big, lds);
+    hipLaunchKernelGGL(k_skm_big, dim3(nbig), dim3(SKM_BIG_NT), lds, st, job, cs);
 }

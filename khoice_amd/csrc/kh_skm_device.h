@@ -100,9 +100,19 @@ template <u32 CAP, u32 RW = 4> constexpr size_t flush_lds_bytes(u32 nbk_alloc) {
 // atomic (LOCAL == false: the scatter, whose buckets are shared by all workgroups) or from a cursor in LDS
 // (LOCAL: the regroup, where a workgroup owns its buckets).  nbk <= 2 * NT.
 // Entry: a barrier has made stage / sid / bcnt visible.  Exit: bcnt zeroed, a barrier passed.
+// Records of a slot whose region is full (regroup, one-word keys): they go to a global side list with the number of
+// their slot; the slots they belong to are taken by a kernel of their own afterwards (k_skm_big).
+struct SkmSpill {
+    uint4* rec = nullptr;     // [cap]
+    u32* slot = nullptr;      // [cap]
+    u32* n = nullptr;         // records spilled so far (may run past cap: the host then falls back)
+    u32 cap = 0;
+    u32 first_slot = 0;       // global number of the workgroup's bucket 0
+};
 template <u32 NT, u32 CAP, bool LOCAL, u32 RW = 4>
 __device__ __forceinline__ void skm_flush(const FlushLds& L, const u32 n, const u32 nbk, u32* cursors,
-                                          uint4* __restrict__ region, const u32 region_cap, u32* __restrict__ ctl) {
+                                          uint4* __restrict__ region, const u32 region_cap, u32* __restrict__ ctl,
+                                          const SkmSpill sp = SkmSpill()) {
     constexpr u32 CS = LOCAL ? 1u : KH_SKM_CUR1_STRIDE;   // words between two cursors
     constexpr int RPT = (int)(CAP / NT);
     const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
@@ -118,14 +128,14 @@ __device__ __forceinline__ void skm_flush(const FlushLds& L, const u32 n, const 
         if (LOCAL) { g = cursors[b0]; cursors[b0] = g + c0; }
         else g = atomicAdd(&cursors[(size_t)b0 * CS], c0);
         L.gpos[b0] = g;
-        if (g + c0 > region_cap) atomicOr(ctl, KH_ERR_CAPACITY);
+        if (g + c0 > region_cap && !sp.rec) atomicOr(ctl, KH_ERR_CAPACITY);
     }
     if (c1) {
         u32 g;
         if (LOCAL) { g = cursors[b1]; cursors[b1] = g + c1; }
         else g = atomicAdd(&cursors[(size_t)b1 * CS], c1);
         L.gpos[b1] = g;
-        if (g + c1 > region_cap) atomicOr(ctl, KH_ERR_CAPACITY);
+        if (g + c1 > region_cap && !sp.rec) atomicOr(ctl, KH_ERR_CAPACITY);
     }
     // the staged records of this thread, into registers (they are placed in place)
     constexpr int Q = (int)(RW / 4);   // uint4 per record
@@ -170,6 +180,9 @@ __device__ __forceinline__ void skm_flush(const FlushLds& L, const u32 n, const 
             if (dest < region_cap) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) region[((u64)b * region_cap + dest) * Q + q] = L.stage[i * Q + q];
+            } else if (Q == 1 && sp.rec) {   // the slot's region is full
+                const u32 at = atomicAdd(sp.n, 1u);
+                if (at < sp.cap) { sp.rec[at] = L.stage[i]; sp.slot[at] = sp.first_slot + b; }
             }
         }
     }

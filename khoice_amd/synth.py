@@ -197,3 +197,52 @@ def species_set(n_species: int, n_genomes: int, length: int, first_species: int 
         for g in range(n_genomes):
             out.append((s, g, clean_text(genome_records(s, g, length, anc))))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# "Hard" genomes: what real bacterial chromosomes have and i.i.d. sequence does not — skewed base
+# composition, insertion-sequence copies, rRNA operons, tandem repeats, homopolymer runs.  They put many
+# instances of the same minimizer into one slot of the super-k-mer form and are what its region / slot
+# capacities are tested against (tests/test_gpu_scale.py, tools/bench_hard.py).
+def _skewed_bases(rng: SplitMix, n: int, gc: float) -> np.ndarray:
+    """n base codes with P(G or C) = gc."""
+    r = rng.take(n)
+    is_gc = (r >> np.uint64(40)) < np.uint64(int(gc * (1 << 24)))
+    low = (r & np.uint64(1)).astype(np.uint8)
+    return np.where(is_gc, np.uint8(1) + low, np.uint8(3) * low).astype(np.uint8)   # C/G or A/T
+
+
+def hard_ancestor(species: int, length: int, gc: float = 0.70) -> np.ndarray:
+    rng = SplitMix(SEED ^ 0x48415244 ^ (species << 32))
+    codes = _skewed_bases(rng, length, gc)
+
+    def paste(piece, copies, divergence):
+        for _ in range(copies):
+            if piece.size >= codes.size:
+                return
+            at = rng.below(codes.size - piece.size)
+            codes[at:at + piece.size] = _substitute(piece, divergence, rng) if divergence else piece
+
+    scale = max(1, length // 5_000_000)
+    paste(_skewed_bases(rng, min(1500, length // 8), gc), 50 * scale, 0.0)        # an insertion sequence, 50 exact copies
+    paste(_skewed_bases(rng, min(5000, length // 8), 0.5), 7 * scale, 0.002)      # rRNA-like operons, nearly identical
+    for _ in range(40 * scale):                                                   # tandem repeats: a 2-60 bp unit, 10-200 times
+        unit = _skewed_bases(rng, 2 + rng.below(59), gc)
+        paste(np.tile(unit, 10 + rng.below(191))[:max(1, length // 16)], 1, 0.0)
+    for _ in range(60 * scale):                                                   # homopolymer runs
+        paste(np.full(12 + rng.below(60), rng.below(4), dtype=np.uint8), 1, 0.0)
+    block = rrna_block(min(50_000, max(0, length // 4)))                          # the block all species share
+    if block.size:
+        at = rng.below(length - block.size + 1)
+        codes[at:at + block.size] = _substitute(block, 0.03, rng)
+    return codes
+
+
+def hard_species_set(n_species: int, n_genomes: int, length: int, gc: float = 0.70):
+    """[(species, genome, cleaned sequence text)] like species_set, on hard ancestors."""
+    out = []
+    for s in range(1, n_species + 1):
+        anc = hard_ancestor(s, length, gc)
+        for g in range(n_genomes):
+            out.append((s, g, clean_text(genome_records(s, g, length, anc))))
+    return out
