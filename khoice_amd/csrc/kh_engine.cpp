@@ -1546,7 +1546,14 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
                     uint64_t* across_hist, u32 hist_len, uint64_t* distinct_per_seq, bool* done, bool by_group = false,
                     SkmRecords* rec_out = nullptr) {
     *done = false;
-    if (k < KH_SKM_MIN_K || k > KH_SKM2_MAX_K || getenv("KHOICE_NO_SKM")) return KH_OK;
+    {
+        // k = 18, 19 on the headline shape: 3.6 / 3.5 ms against 4.5 with key arrays; k = 17 with minimizers of 11 bases
+        // overfills too many slots, with 12 (windows of 6) the scatter alone takes 2 ms: below 18 the key arrays stay
+        // (KHOICE_SKM_MIN_K: experiments and tests, the kernels take k >= 15)
+        int min_k = KH_SKM_MIN_K;
+        if (const char* e = getenv("KHOICE_SKM_MIN_K")) min_k = std::max(15, atoi(e));
+        if (k < min_k || k > KH_SKM2_MAX_K || getenv("KHOICE_NO_SKM")) return KH_OK;
+    }
     const bool two = k > KH_SKM_MAX_K;   // two-word keys: 32-byte records, kh_skm2.hip
     if (two && getenv("KHOICE_NO_SKM2")) return KH_OK;
     if ((!by_group && nseq > KH_TAG_MAX_OPS) || ngroups > KH_TAG_MAX_OPS) return KH_OK;
@@ -1573,6 +1580,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     if (!two) {
         const int m15w = k - 15 + 1;                                   // m-mers per k-mer with m = 15
         m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;   // m = 16 when that makes w a power of two
+        if (k < 20) m = std::max(11, k - 6);                           // short k-mers: windows of 7 (5 at k = 15) shorter m-mers (hot minimizers: k_skm_big)
         if (const char* e = getenv("KHOICE_SKM_M")) m = std::min(16, std::max(2, atoi(e)));   // experiments
         if (m >= k) return KH_OK;
         w = (u32)(k - m + 1);
@@ -2435,7 +2443,8 @@ extern "C" int kh_skm_exchange_plan(kh_ctx* c, int k, uint64_t positions_max, ui
     if (!c || !nslots || !slots_per_part || !part_cap || nparts < 1) return kh_fail(KH_E_ARG, "kh_skm_exchange_plan: bad argument");
     if (!skm_exchange_k(k)) return kh_fail(KH_E_ARG, "the exchange form takes k = %d .. %d", KH_SKM_MIN_K, KH_SKM_MAX_K);
     const int m15w = k - 15 + 1;
-    const int m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;
+    int m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;
+    if (k < 20) m = std::max(11, k - 6);
     const u32 w = (u32)(k - m + 1);
     // k-mer instances per slot and rank: the pack kernel takes 1024 records of a slot; the owner's table (4096 entries)
     // has to hold the slot's distinct k-mers of ALL ranks — sized for unrelated groups: nparts x the per-rank mean

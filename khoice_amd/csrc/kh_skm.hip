@@ -473,11 +473,12 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
     }
     if (tid < SKM_HSTRIPE_WORDS) hstripe[tid] = 0;
     if (tid == 0) scratch[0] = 0;
-    // the 2k-bit mask and where the last base of a k-mer sits, as 32-bit halves (20 <= k <= 32: the low word is full)
-    const u32 kmh = (u32)(kh_mask(2 * k) >> 32);
+    // the 2k-bit mask and where the last base of a k-mer sits, as 32-bit halves (15 <= k <= 32)
+    const u32 kml = (u32)kh_mask(2 * k), kmh = (u32)(kh_mask(2 * k) >> 32);
     const u32 fsh = 64u - 2u * (u32)k;          // right-aligns a reversed window
-    const u32 tsh = 2u * (u32)k - 2u;           // 38 .. 62
-    const u32 tsh_hi = tsh - 32u;               // 6 .. 30
+    const u32 tsh = 2u * (u32)k - 2u;           // 28 .. 62
+    const bool tsh_high = tsh >= 32u;           // (uniform) the last base of a k-mer sits in the high word
+    const u32 tsh_sub = tsh_high ? tsh - 32u : tsh;
     // one distinct k-mer: popcount of its mask per group -> the group's bin; number of groups -> across bin
     // (returns true when the k-mer sits in exactly one group — nearly all do: those are counted per wave)
     auto eval_mask = [&](u32 mlo, u32 mhi) -> bool {
@@ -640,18 +641,19 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
                     const u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
                     const u32 sh = 2u * first;   // 0, 2E, .. <= 60
                     const u64 lo = sh ? (clo >> sh) | (chi << (64u - sh)) : clo, hi = chi >> sh;
-                    const u32 xl = (u32)lo, xh = (u32)(lo >> 32) & kmh;   // the first k-mer, base j at bits 2j
+                    const u32 xl = (u32)lo & kml, xh = (u32)(lo >> 32) & kmh;   // the first k-mer, base j at bits 2j
                     const u64 fw = kh_revpairs64(((u64)xh << 32) | xl) >> fsh;
-                    u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl, rh = ~xh & kmh;
+                    u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl & kml, rh = ~xh & kmh;
                     const u32 t = (u32)((lo >> tsh) | (hi << (64u - tsh)));   // bits 2e: the last base of the chunk's k-mer e
                     const u32 tc = ~t;
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         if (e) {   // roll both strands by one base
                             fh = __builtin_amdgcn_alignbit(fh, fl, 30) & kmh;
-                            fl = (fl << 2) | ((t >> (2 * e)) & 3u);
+                            fl = ((fl << 2) | ((t >> (2 * e)) & 3u)) & kml;
                             rl = __builtin_amdgcn_alignbit(rh, rl, 2);
-                            rh = (rh >> 2) | (((tc >> (2 * e)) & 3u) << tsh_hi);
+                            rh >>= 2;
+                            if (tsh_high) rh |= ((tc >> (2 * e)) & 3u) << tsh_sub; else rl |= ((tc >> (2 * e)) & 3u) << tsh_sub;
                         }
                         const bool fwd = fh < rh || (fh == rh && fl < rl);
                         const u32 cl = fwd ? fl : rl, ch = fwd ? fh : rh;
@@ -849,7 +851,9 @@ __global__ __launch_bounds__(SKM_BIG_NT) void k_skm_big(const KhSkmJob jb, u32 c
     const int k = jb.k;
     const u32 slot = jb.big_list[blockIdx.x];
     const u32 sshift = nbins <= 72u ? 2u : (nbins <= 144u ? 1u : 0u), smask = (1u << sshift) - 1u;
-    const u32 kmh = (u32)(kh_mask(2 * k) >> 32), fsh = 64u - 2u * (u32)k, tsh = 2u * (u32)k - 2u, tsh_hi = tsh - 32u;
+    const u32 kml = (u32)kh_mask(2 * k), kmh = (u32)(kh_mask(2 * k) >> 32), fsh = 64u - 2u * (u32)k, tsh = 2u * (u32)k - 2u;
+    const bool tsh_high = tsh >= 32u;
+    const u32 tsh_sub = tsh_high ? tsh - 32u : tsh;
     if (tid < (u32)KH_TAG_MAX_OPS) {
         const u32 g = jb.ginfo[tid], g0 = g & 0xffu, gn = (g >> 8) & 0xffu;
         const u64 gm = gn ? (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0 : 0ull;
@@ -948,18 +952,19 @@ __global__ __launch_bounds__(SKM_BIG_NT) void k_skm_big(const KhSkmJob jb, u32 c
                 const u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
                 const u32 sh = 2u * first;
                 const u64 lo = sh ? (clo >> sh) | (chi << (64u - sh)) : clo, hi = chi >> sh;
-                const u32 xl = (u32)lo, xh = (u32)(lo >> 32) & kmh;
+                const u32 xl = (u32)lo & kml, xh = (u32)(lo >> 32) & kmh;
                 const u64 fw = kh_revpairs64(((u64)xh << 32) | xl) >> fsh;
-                u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl, rh = ~xh & kmh;
+                u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl & kml, rh = ~xh & kmh;
                 const u32 t = (u32)((lo >> tsh) | (hi << (64u - tsh)));
                 const u32 tc = ~t;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     if (e) {
                         fh = __builtin_amdgcn_alignbit(fh, fl, 30) & kmh;
-                        fl = (fl << 2) | ((t >> (2 * e)) & 3u);
+                        fl = ((fl << 2) | ((t >> (2 * e)) & 3u)) & kml;
                         rl = __builtin_amdgcn_alignbit(rh, rl, 2);
-                        rh = (rh >> 2) | (((tc >> (2 * e)) & 3u) << tsh_hi);
+                        rh >>= 2;
+                        if (tsh_high) rh |= ((tc >> (2 * e)) & 3u) << tsh_sub; else rl |= ((tc >> (2 * e)) & 3u) << tsh_sub;
                     }
                     if ((u32)e >= cnt) break;
                     const bool fwd = fh < rh || (fh == rh && fl < rl);
@@ -1132,7 +1137,9 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
     const u32 tid0 = threadIdx.x;
     u32 tid = tid0, lane = lane_id();
     const int k = jb.k;
-    const u32 kmh = (u32)(kh_mask(2 * k) >> 32), fsh = 64u - 2u * (u32)k, tsh = 2u * (u32)k - 2u, tsh_hi = tsh - 32u;
+    const u32 kml = (u32)kh_mask(2 * k), kmh = (u32)(kh_mask(2 * k) >> 32), fsh = 64u - 2u * (u32)k, tsh = 2u * (u32)k - 2u;
+    const bool tsh_high = tsh >= 32u;
+    const u32 tsh_sub = tsh_high ? tsh - 32u : tsh;
     const u32 hbins = jb.hist_len < SKM_PH_HBINS ? jb.hist_len : SKM_PH_HBINS;   // counts below this: LDS; above: global atomics
     typedef const u32 __attribute__((address_space(4))) * ConstU32;
     if (tid < SKM_PH_HBINS) lhist[tid] = 0;
@@ -1215,18 +1222,19 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
                     const u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
                     const u32 sh = 2u * first;
                     const u64 lo = sh ? (clo >> sh) | (chi << (64u - sh)) : clo, hi = chi >> sh;
-                    const u32 xl = (u32)lo, xh = (u32)(lo >> 32) & kmh;
+                    const u32 xl = (u32)lo & kml, xh = (u32)(lo >> 32) & kmh;
                     const u64 fw = kh_revpairs64(((u64)xh << 32) | xl) >> fsh;
-                    u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl, rh = ~xh & kmh;
+                    u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl & kml, rh = ~xh & kmh;
                     const u32 t = (u32)((lo >> tsh) | (hi << (64u - tsh)));
                     const u32 tc = ~t;
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         if (e) {
                             fh = __builtin_amdgcn_alignbit(fh, fl, 30) & kmh;
-                            fl = (fl << 2) | ((t >> (2 * e)) & 3u);
+                            fl = ((fl << 2) | ((t >> (2 * e)) & 3u)) & kml;
                             rl = __builtin_amdgcn_alignbit(rh, rl, 2);
-                            rh = (rh >> 2) | (((tc >> (2 * e)) & 3u) << tsh_hi);
+                            rh >>= 2;
+                            if (tsh_high) rh |= ((tc >> (2 * e)) & 3u) << tsh_sub; else rl |= ((tc >> (2 * e)) & 3u) << tsh_sub;
                         }
                         if ((u32)e >= cnt) break;
                         const bool fwd = fh < rh || (fh == rh && fl < rl);
