@@ -1679,9 +1679,9 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     }
     seq_bytes += 256;
     const u32 ntiles = (u32)tiles.size();
-    // one-word keys: the union is persistent (as many workgroups as fit the chip, each with a histogram of its own)
-    const u32 ugrid = std::min<u32>(nslots, kh_skm_union_per_cu(table) * (u32)std::max(1, c->cus));
-    const u32 reps = two ? std::min<u32>(256, std::max<u32>(1, nslots)) : ugrid;
+    // the union is persistent (as many workgroups as fit the chip, each with a histogram of its own)
+    const u32 ugrid = std::min<u32>(nslots, (two ? 2u : kh_skm_union_per_cu(table)) * (u32)std::max(1, c->cus));
+    const u32 reps = ugrid;
     const size_t hist_words = (size_t)reps * nbins;
     // workspace: [hist][ctl: 8 u32][inst: nseq u64][dup: 64 u64][cur1: nb1 u32][cur2: nslots u32] (zeroed) [ginfo: 64 u32]
     const size_t off_ctl = 8 * hist_words, off_inst = off_ctl + 32, off_dup = off_inst + 8 * (size_t)nseq,
@@ -1801,7 +1801,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         return KH_OK;
     }
     c->prof_begin(KC_SKM_UNION);
-    if (two) kh_launch_skm2_union(job, cs, st);
+    if (two) kh_launch_skm2_union(job, cs, ugrid, st);
     else kh_launch_skm_union(job, cs, ugrid, st);
     c->prof_end();
     HIPCHK(hipGetLastError());

@@ -213,7 +213,7 @@ size_t kh_skm2_regroup_lds_bytes(u32 S);
 size_t kh_skm2_union_lds_bytes(u32 nbins);
 void kh_launch_skm2_scatter(const KhSkmJob& job, u32 ntiles, hipStream_t st);
 void kh_launch_skm2_regroup(const KhSkmJob& job, hipStream_t st);
-void kh_launch_skm2_union(const KhSkmJob& job, u32 cs, hipStream_t st);
+void kh_launch_skm2_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st);   // persistent, as the one-word union
 
 struct KhLookback {      // workspace of one ordered single-pass launch
     u64* desc;           // [nparts] tile descriptors, zeroed before launch

@@ -304,269 +304,353 @@ __global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm2_regroup(const KhSkmJob jb
 }
 
 // ------------------------------------------------------------------------------------------
-// S2b: one slot per workgroup -> LDS hash set {128-bit canonical k-mer, genome mask} -> histogram bins
+// S2b: LDS hash set {128-bit canonical k-mer, genome mask} per slot -> histogram bins.  The same plan as the one-word
+// union of kh_skm.hip (which see): PERSISTENT workgroups with the next slot's record on its way while this one is
+// worked on; identical records (the same piece of sequence in several genomes of a group) merged before anything is
+// expanded; chunks of two consecutive k-mers per thread, the second by rolling both strands; every thread turns the
+// entries it created into histogram bins once the masks are final.
 // ------------------------------------------------------------------------------------------
-#ifndef KH_TUNE_SKM2_UNT
-#define KH_TUNE_SKM2_UNT 1024   // two workgroups per CU = 8 waves per SIMD (512: 5.0 ms against 3.5 at k = 41)
-#endif
-constexpr u32 SKM2_UNT = KH_TUNE_SKM2_UNT, SKM2_UT = 2048, SKM2_UE = SKM2_UT / SKM2_UNT, SKM2_UT2 = 128;
-constexpr u32 SKM2_UNW = SKM2_UNT / 64;
-constexpr u32 SKM2_URPT = 1024 / SKM2_UNT;         // records per thread when the slot is read: cap2 <= 1024
-constexpr u32 SKM2_SPEC = 320;                     // records of a slot read before their number is known
-constexpr u32 SKM2_OWN = 8192;                     // chunk owners: a slot of up to SKM2_UE * 8192 k-mer instances (a block shared by a hundred genomes lands in few slots)
-size_t kh_skm2_union_lds_bytes(u32 nbins) {
-    return (size_t)SKM2_UT * 24 + (size_t)SKM2_UT2 * 24 + 256 + 128 + 256 + (((size_t)nbins * 32 + 15) & ~(size_t)15) +
-           (size_t)(SKM2_URPT * SKM2_UNT + 8) * 2 + (size_t)SKM2_OWN * 2;
+constexpr u32 SKM2_UNT = 1024, SKM2_UT = 2048, SKM2_UT2 = 64, SKM2_HBITS = 11;
+constexpr u32 SKM2_UE = 2;                         // k-mers per chunk
+constexpr u32 SKM2_OB = 5;                         // bits of a chunk's number inside its record (n <= 63)
+constexpr u32 SKM2_MAXREC = 512;                   // records of a slot: staged in the low key plane (16 KB)
+constexpr u32 SKM2_PASSES = 3;
+constexpr u32 SKM2_MAXCH = SKM2_PASSES * SKM2_UNT; // chunks of a slot after the merge
+constexpr u32 SKM2_HSTRIPE_WORDS = 288;
+size_t kh_skm2_union_lds_bytes(u32) {
+    return (size_t)SKM2_UT * 24 + (size_t)SKM2_UT2 * 24 + 1024 + 128 + 256 + (size_t)SKM2_HSTRIPE_WORDS * 4 + (size_t)SKM2_MAXCH * 2 +
+           (size_t)SKM2_MAXREC * 4;
 }
-u32 kh_skm2_max_cap2() { return SKM2_URPT * SKM2_UNT; }
+u32 kh_skm2_max_cap2() { return SKM2_MAXREC; }
 u32 kh_skm2_table() { return SKM2_UT; }
 
-__global__ __launch_bounds__(SKM2_UNT, 2 * (SKM2_UNT / 64) / 4) void k_skm2_union(const KhSkmJob jb, u32 cs) {
+__device__ __forceinline__ u32 key2_hash(u64 lo, u64 hi) { return ((u32)lo ^ (u32)(lo >> 32) ^ (u32)hi ^ (u32)(hi >> 32)) * 0x9E3779B1u; }
+
+__global__ __launch_bounds__(SKM2_UNT, 8) void k_skm2_union(const KhSkmJob jb, u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
-    constexpr u32 NT = SKM2_UNT, T = SKM2_UT, T2 = SKM2_UT2, HBITS = 11;
+    constexpr u32 NT = SKM2_UNT, T = SKM2_UT, T2 = SKM2_UT2, HBITS = SKM2_HBITS, NW = NT / 64;
     constexpr int E = (int)SKM2_UE;
     constexpr u64 EMPTY = ~0ull;   // never the low word of a canonical key for k <= 63 (see the head of the file)
-    struct Tbl { unsigned long long* klo; unsigned long long* khi; u32* mlo; u32* mhi; };
     u8* p = lds_raw;
-    Tbl tbl, ovf;
-    tbl.klo = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T * 8;
-    tbl.khi = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T * 8;
-    tbl.mlo = reinterpret_cast<u32*>(p);                      p += (size_t)T * 4;
-    tbl.mhi = reinterpret_cast<u32*>(p);                      p += (size_t)T * 4;
-    ovf.klo = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T2 * 8;
-    ovf.khi = reinterpret_cast<unsigned long long*>(p);       p += (size_t)T2 * 8;
-    ovf.mlo = reinterpret_cast<u32*>(p);                      p += (size_t)T2 * 4;
-    ovf.mhi = reinterpret_cast<u32*>(p);                      p += (size_t)T2 * 4;
-    u32* ginfo = reinterpret_cast<u32*>(p);                   p += 256;
-    u32* scratch = reinterpret_cast<u32*>(p);                 p += 128;
-    u32* dupc = reinterpret_cast<u32*>(p);                    p += 256;
-    u32* hstripe = reinterpret_cast<u32*>(p);                 p += ((size_t)jb.nbins * 32 + 15) & ~(size_t)15;
-    u16* roff = reinterpret_cast<u16*>(p);                    p += (size_t)(SKM2_URPT * NT + 8) * 2;
-    u16* owner = reinterpret_cast<u16*>(p);
-    const u32 tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    const u32 nbins = jb.nbins, cap2 = jb.cap2;
+    unsigned long long* tklo = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T * 8;
+    unsigned long long* tkhi = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T * 8;
+    u32* tmlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T * 4;
+    u32* tmhi = reinterpret_cast<u32*>(p);                                 p += (size_t)T * 4;
+    unsigned long long* oklo = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T2 * 8;
+    unsigned long long* okhi = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T2 * 8;
+    u32* omlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
+    u32* omhi = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
+    uint4* gtab = reinterpret_cast<uint4*>(p);                             p += 1024;
+    u32* scratch = reinterpret_cast<u32*>(p);                              p += 128;
+    u32* dupc = reinterpret_cast<u32*>(p);                                 p += 256;
+    u32* hstripe = reinterpret_cast<u32*>(p);                              p += (size_t)SKM2_HSTRIPE_WORDS * 4;
+    u16* owner = reinterpret_cast<u16*>(p);                                p += (size_t)SKM2_MAXCH * 2;
+    u32* rmask = reinterpret_cast<u32*>(p);
+    // the records are staged in the low key plane (32 bytes each), the set of their contents is the high key plane
+    uint4* stage = reinterpret_cast<uint4*>(tklo);
+    u32* dd = reinterpret_cast<u32*>(tkhi);   // [T * 2] record number + 1
+    constexpr u32 DD = 2 * T;
+    const u32 tid0 = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    u32 tid = tid0, lane = lane_id();
+    const u32 nbins = jb.nbins, cap2 = jb.cap2, nslots = jb.nslots, stride = gridDim.x;
     const int k = jb.k;
-    const u32 slot = blockIdx.x;
-    const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2 * 2;
-    // ---- the k-mer counts of the slot's records (the last word of each), SKM2_URPT consecutive records per thread
-    const u32 have = jb.cur2[slot];
-    u32 top[SKM2_URPT];
-#pragma unroll
-    for (u32 j = 0; j < SKM2_URPT; ++j) {
-        const u32 i = SKM2_URPT * tid + j;
-        top[j] = i < (cap2 < SKM2_SPEC ? cap2 : SKM2_SPEC) ? reg[2 * i + 1].w : 0u;
-    }
-    auto clear_tables = [&]() {   // key words all ones (low: empty, high: not yet published), masks zero
-        uint4* k4 = reinterpret_cast<uint4*>(tbl.klo);    // T * 16 bytes of ones (both key planes), then T * 8 bytes of zeros
-        uint4* m4 = reinterpret_cast<uint4*>(tbl.mlo);
-        for (u32 i = tid; i < T; i += NT) k4[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-        for (u32 i = tid; i < T / 2; i += NT) m4[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (u32 i = tid; i < T2; i += NT) { ovf.klo[i] = EMPTY; ovf.khi[i] = EMPTY; ovf.mlo[i] = 0u; ovf.mhi[i] = 0u; }
-    };
-    for (u32 i = tid; i < (u32)KH_TAG_MAX_OPS; i += NT) { ginfo[i] = jb.ginfo[i]; dupc[i] = 0; }
-    for (u32 i = tid; i < nbins * 8u; i += NT) hstripe[i] = 0;
-    clear_tables();
-    const u32 nrec = have < cap2 ? have : cap2;
-    if (nrec > SKM2_SPEC) {   // uniform, rare
-#pragma unroll
-        for (u32 j = 0; j < SKM2_URPT; ++j) {
-            const u32 i = SKM2_URPT * tid + j;
-            if (i >= SKM2_SPEC && i < nrec) top[j] = reg[2 * i + 1].w;
-        }
-    }
-    u32 nj[SKM2_URPT], mine = 0;
-#pragma unroll
-    for (u32 j = 0; j < SKM2_URPT; ++j) {
-        nj[j] = SKM2_URPT * tid + j < nrec ? rec2_n(top[j]) : 0u;
-        mine += nj[j];
-    }
-    const u32 incl = wave_scan_add(mine);
-    if (lane == KH_WAVE - 1) scratch[wid] = incl;
-    __syncthreads();
-    u32 off = incl - mine, N = 0;
-    for (u32 q = 0; q < SKM2_UNW; ++q) {
-        const u32 v = scratch[q];
-        off += q < wid ? v : 0u;
-        N += v;
-    }
-    if (tid == 0 && N > T) atomicMax(jb.ctl + 1, N);
-    if (N > (u32)E * SKM2_OWN) {   // uniform: a slot this full goes back to the host
-        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
-        N = 0;
-    }
-    if (N) {
-#pragma unroll
-        for (u32 j = 0; j < SKM2_URPT; ++j) {
-            if (nj[j]) {
-                roff[SKM2_URPT * tid + j] = (u16)off;
-                for (u32 c = (off + (u32)E - 1) / (u32)E; c <= (off + nj[j] - 1) / (u32)E; ++c) owner[c] = (u16)(SKM2_URPT * tid + j);
-                off += nj[j];
-            }
-        }
-    }
-    __syncthreads();
-    const u32 R = (N + T - 1) / T;   // key subsets handled one after the other (1 unless the slot is overfull)
-    // the 2k-bit mask and the shift that right-aligns a reversed 128-bit window, as 32-bit words (uniform)
+    const u32 sshift = nbins <= 72u ? 2u : (nbins <= 144u ? 1u : 0u), smask = (1u << sshift) - 1u;
+    // the 2k-bit mask, the shift that right-aligns a reversed 128-bit window, where the last base sits (33 <= k <= 63)
     const u32 kb = 2 * (u32)k;          // 66 .. 126
     u32 km[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) km[i] = kb >= 32u * (i + 1) ? 0xffffffffu : (kb > 32u * i ? (1u << (kb - 32u * i)) - 1u : 0u);
+    const u64 kmhi = ((u64)km[3] << 32) | km[2];
     const u32 fs = 128u - kb;           // 2 .. 62
-    auto eval_mask = [&](u64 mask, u32 g) -> u32 {
-        u32 ng = 0;
-        while (true) {
-            const u32 g0 = g & 0xffu, gn = (g >> 8) & 0xffu, bin0 = g >> 16;
-            const u64 gm = (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0;
-            u32 c = (u32)__popcll(mask & gm);
-            c = c < cs ? c : cs;
-            atomicAdd(&hstripe[(bin0 + c) * 8u + (lane & 7u)], 1u);
-            mask &= ~gm;
-            ++ng;
-            if (!mask) break;
-            g = ginfo[__ffsll((unsigned long long)mask) - 1];
-        }
-        return ng < cs ? ng : cs;
-    };
-    for (u32 q = 0; q < R; ++q) {
-        if (q) { clear_tables(); __syncthreads(); }
-        for (u32 base = 0; base < N; base += NT * (u32)E) {
-            const u32 j0 = base + (u32)E * tid;
-            u64 klo[E], khi[E];
-            u32 tagp = 0, slot_[E], act = 0;
-            if (j0 < N) {
-                u32 ri = owner[j0 / (u32)E];
-                u32 o = j0 - roff[ri];
-                uint4 a = reg[2 * ri], b = reg[2 * ri + 1];
-                u32 cn = rec2_n(b.w), ctag = rec2_tag(b.w);
+    const u32 tsh = kb - 2u - 64u;      // where the last base sits in the high word: 0 .. 60
+    auto clear_keys = [&]() {   // key words all ones (low: empty, high: not yet published)
+        uint4* k4 = reinterpret_cast<uint4*>(tklo);
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    klo[e] = EMPTY;
-                    khi[e] = 0;
-                    slot_[e] = 0;
-                    if (j0 + (u32)e < N) {
-                        if (o == cn) {
-                            ++ri;
-                            const u32 rj = ri < nrec ? ri : nrec - 1;
-                            a = reg[2 * rj];
-                            b = reg[2 * rj + 1];
-                            cn = rec2_n(b.w);
-                            ctag = rec2_tag(b.w);
-                            o = 0;
-                        }
-                        // the 2k bits of the k-mer that starts at base o: words q .. q + 4 of the record, funnel-shifted
-                        const u32 sh = 2 * o, wq = sh >> 5, r5 = sh & 31u;
-                        const u32 R0 = a.x, R1 = a.y, R2 = a.z, R3 = a.w, R4 = b.x, R5 = b.y, R6 = b.z, R7 = b.w & 0x3ffu;
-                        const bool q1 = wq & 1u, q2 = wq & 2u;
-                        auto sel = [&](u32 v0, u32 v1, u32 v2, u32 v3) -> u32 {
-                            const u32 lo2 = q1 ? v1 : v0, hi2 = q1 ? v3 : v2;
-                            return q2 ? hi2 : lo2;
-                        };
-                        const u32 s0 = sel(R0, R1, R2, R3), s1 = sel(R1, R2, R3, R4), s2 = sel(R2, R3, R4, R5),
-                                  s3 = sel(R3, R4, R5, R6), s4 = sel(R4, R5, R6, R7);
-                        u32 x[4];
-                        x[0] = __builtin_amdgcn_alignbit(s1, s0, r5) & km[0];
-                        x[1] = __builtin_amdgcn_alignbit(s2, s1, r5) & km[1];
-                        x[2] = __builtin_amdgcn_alignbit(s3, s2, r5) & km[2];
-                        x[3] = __builtin_amdgcn_alignbit(s4, s3, r5) & km[3];
-                        // forward key: the window with the order of its bases reversed, right-aligned
-                        const u32 y0 = revpairs32(x[3]), y1 = revpairs32(x[2]), y2 = revpairs32(x[1]), y3 = revpairs32(x[0]);
-                        const u64 ylo = ((u64)y1 << 32) | y0, yhi = ((u64)y3 << 32) | y2;
-                        const u64 flo = (ylo >> fs) | ((yhi << 1) << (63 - fs)), fhi = yhi >> fs;
-                        // reverse complement key: the complemented window
-                        const u64 rlo = ((u64)(x[1] ^ km[1]) << 32) | (x[0] ^ km[0]), rhi = ((u64)(x[3] ^ km[3]) << 32) | (x[2] ^ km[2]);
-                        const bool fwd = fhi < rhi || (fhi == rhi && flo < rlo);
-                        const u64 clo = fwd ? flo : rlo, chi = fwd ? fhi : rhi;
-                        const u32 h = ((u32)clo ^ (u32)(clo >> 32) ^ (u32)chi ^ (u32)(chi >> 32)) * 0x9E3779B1u;
-                        klo[e] = clo;
-                        khi[e] = chi;
-                        slot_[e] = h >> (32 - HBITS);
-                        tagp |= ctag << (8 * e);
-                        if (R == 1 || (((h >> 4) & 0xffffu) * R) >> 16 == q) act |= 1u << e;
-                        ++o;
+        for (u32 e = 0; e < T / NT; ++e) k4[e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    };
+    auto clear_masks = [&]() {
+        reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);   // (both mask planes: T * 8 bytes = NT uint4)
+        unsigned long long e0 = EMPTY;
+        asm volatile("" : "+v"(e0));
+        if (tid < T2) { oklo[tid] = e0; okhi[tid] = e0; omlo[tid] = 0u; omhi[tid] = 0u; }
+    };
+    typedef const u32 __attribute__((address_space(4))) * ConstU32;
+    const ConstU32 counts = (ConstU32)(unsigned long long)jb.cur2;
+    const u32 fit = cap2 < SKM2_MAXREC ? cap2 : SKM2_MAXREC;
+    auto count_of = [&](u32 sl) -> u32 {
+        const u32 n = sl < nslots ? counts[sl] : 0u;
+        return n < fit ? n : fit;
+    };
+    if (tid < (u32)KH_TAG_MAX_OPS) {
+        const u32 g = jb.ginfo[tid], g0 = g & 0xffu, gn = (g >> 8) & 0xffu;
+        const u64 gm = gn ? (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0 : 0ull;
+        gtab[tid] = make_uint4((u32)gm, (u32)(gm >> 32), (g >> 16) << sshift, 0u);
+        dupc[tid] = 0;
+    }
+    if (tid < SKM2_HSTRIPE_WORDS) hstripe[tid] = 0;
+    if (tid == 0) scratch[0] = 0;
+    auto eval_mask = [&](u32 mlo, u32 mhi) -> bool {
+        const u32 lsel = lane & smask;
+        u32 ng = 0;
+        do {
+            const u32 first = mlo ? (u32)__builtin_ctz(mlo) : 32u + (u32)__builtin_ctz(mhi);
+            const uint4 g = gtab[first];
+            u32 c = (u32)__popc(mlo & g.x) + (u32)__popc(mhi & g.y);
+            c = c < cs ? c : cs;
+            atomicAdd(&hstripe[g.z + (c << sshift) + lsel], 1u);
+            const u32 keep_hi = mlo ? ~0u : mhi - 1u;
+            mlo &= ~g.x & (mlo - 1u);
+            mhi &= ~g.y & keep_hi;
+            ++ng;
+        } while (mlo | mhi);
+        if (ng == 1u) return true;
+        atomicAdd(&hstripe[((jb.abase + (ng < cs ? ng : cs)) << sshift) + lsel], 1u);
+        return false;
+    };
+    u32 st_full = 0, st_exp = 0;
+    u32 slot = blockIdx.x;
+    u32 nrec = count_of(slot);
+    u32 nrec_next = count_of(slot + stride);
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+    if (tid < nrec) { const uint4* r = jb.reg2 + ((u64)slot * cap2 + tid) * 2; ra = r[0]; rb = r[1]; }
+    for (; slot < nslots; slot += stride) {
+        tid = tid0;
+        asm volatile("" : "+v"(tid));
+        lane = tid & (KH_WAVE - 1u);
+        const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2 * 2;
+        const u32 nrec_after = count_of(slot + 2u * stride);
+        if (counts[slot] > fit && tid0 == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);   // (no side list with two-word keys: the host falls back)
+        // ---- stage this slot's records, one per thread
+        u32 nj = 0;
+        const u32 tg = rec2_tag(rb.w);
+        const u32 a0 = ra.x, a1 = ra.y, a2 = ra.z, a3 = ra.w, b0 = rb.x, b1 = rb.y, b2 = rb.z, b3 = rb.w;
+        {
+            u32 z = 0;
+            asm volatile("" : "+v"(z));
+            reinterpret_cast<uint4*>(dd)[tid] = make_uint4(z, z, z, z);   // DD = 4096 entries = NT uint4
+        }
+        if (tid < nrec) {
+            nj = rec2_n(b3);
+            stage[2 * tid] = ra;
+            stage[2 * tid + 1] = rb;
+            rmask[tid] = 1u << (tg & 31u);
+        }
+        __syncthreads();
+        // ---- identical records meet
+        if (__builtin_amdgcn_ballot_w64(nj != 0)) {
+            u32 h = a0 * 0x9E3779B1u ^ a1 * 0x85EBCA77u ^ a2 * 0xC2B2AE3Du ^ a3 * 0x27D4EB2Fu ^ b0 * 0x165667B1u ^ b1 * 0xD3A2646Cu ^
+                    b2 * 0xFD7046C5u ^ (b3 & ~(63u << 20)) * 0xB55A4F09u;
+            h ^= h >> 15;
+            h *= 0x2C1B3C6Du;
+            u32 hp = h >> 20;   // DD = 4096
+            const u32 nch = (nj + (u32)E - 1u) / (u32)E;
+            bool pend = nj != 0, won = false;
+            while (__builtin_amdgcn_ballot_w64(pend)) {
+                if (pend) {
+                    const u32 old = atomicCAS(&dd[hp], 0u, tid + 1u);
+                    if (old == 0u) { won = true; pend = false; }
+                    else {
+                        const uint4 oa = stage[2 * (old - 1u)], ob = stage[2 * (old - 1u) + 1];
+                        if (oa.x == a0 && oa.y == a1 && oa.z == a2 && oa.w == a3 && ob.x == b0 && ob.y == b1 && ob.z == b2 &&
+                            ((ob.w ^ b3) & ~(31u << 20)) == 0u) {   // the same bases and number of k-mers, a genome of the same half
+                            const u32 bit = 1u << (tg & 31u);
+                            const u32 was = atomicOr(&rmask[old - 1u], bit);
+                            if (was & bit) atomicAdd(&dupc[tg], nj);
+                            pend = false;
+                        } else hp = (hp + 1u) & (DD - 1u);
                     }
                 }
-            } else {
+            }
+            const u32 mine = won ? (nch | (nj << 16)) : 0u;
+            const u32 incl = wave_scan_add(mine);
+            u32 wbase = 0;
+            if (lane == KH_WAVE - 1 && incl) wbase = atomicAdd(&scratch[0], incl);
+            wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
+            if (won) {
+                const u32 cstart = (wbase + incl - mine) & 0xffffu;
+                if (cstart + nch <= SKM2_MAXCH) {
+                    for (u32 cc = 0; cc < nch; ++cc) owner[cstart + cc] = (u16)((tid << SKM2_OB) | cc);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the next slot's record sets out; the table is made
+        ra = make_uint4(0, 0, 0, 0); rb = make_uint4(0, 0, 0, 0);
+        if (tid < nrec_next) { const uint4* r = jb.reg2 + ((u64)(slot + stride) * cap2 + tid) * 2; ra = r[0]; rb = r[1]; }
+        clear_keys();
+        clear_masks();
+        u32 C = scratch[0] & 0xffffu, N = scratch[0] >> 16;
+        st_full = N > st_full ? N : st_full;
+        st_exp += N;
+        if (C > SKM2_MAXCH) {
+            if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+            C = 0;
+            N = 0;
+        }
+        __syncthreads();
+        if (tid == 0) scratch[0] = 0;
+        const u32 R = (N + T - 1) / T;
+        const u32 ctid = (((wid + ((slot * 2654435761u) >> 16)) & (NW - 1u)) << 6) | lane;
+        for (u32 q = 0; q < R; ++q) {
+            if (q) { clear_keys(); clear_masks(); __syncthreads(); }
+            u32 made[SKM2_PASSES];
+#pragma unroll
+            for (u32 ps = 0; ps < SKM2_PASSES; ++ps) made[ps] = 0u;
+            u32 ones = 0;
+#pragma unroll
+            for (u32 pass = 0; pass < SKM2_PASSES; ++pass) {
+                if (pass * NT >= C) break;
+                const u32 c = pass * NT + ctid;
+                u64 klo[E], khi[E];
+                u32 slot_[E], act = 0, bits = 0, half = 0;
 #pragma unroll
                 for (int e = 0; e < E; ++e) { klo[e] = EMPTY; khi[e] = 0; slot_[e] = 0; }
-            }
-            auto tag = [&](int e) -> u32 { return (tagp >> (8 * e)) & 63u; };
-            auto khash = [&](int e) -> u32 {
-                return ((u32)klo[e] ^ (u32)(klo[e] >> 32) ^ (u32)khi[e] ^ (u32)(khi[e] >> 32)) * 0x9E3779B1u;
-            };
-            u32 was[E];
+                if (c < C) {
+                    const u32 o = owner[c], ri = o >> SKM2_OB, first = (o & ((1u << SKM2_OB) - 1u)) * (u32)E;
+                    const uint4 a = reg[2 * ri], b = reg[2 * ri + 1];
+                    bits = rmask[ri];
+                    half = (b.w >> 25) & 1u;
+                    const u32 left = rec2_n(b.w) - first;
+                    const u32 cnt = left < (u32)E ? left : (u32)E;
+                    // 128 bits of the record from base `first` on: words wq .. wq + 4, funnel-shifted
+                    const u32 sh = 2 * first, wq = sh >> 5, r5 = sh & 31u;
+                    const u32 R0 = a.x, R1 = a.y, R2 = a.z, R3 = a.w, R4 = b.x, R5 = b.y, R6 = b.z, R7 = b.w & 0x3ffu;
+                    const bool q1 = wq & 1u, q2 = wq & 2u;
+                    auto sel = [&](u32 v0, u32 v1, u32 v2, u32 v3) -> u32 {
+                        const u32 lo2 = q1 ? v1 : v0, hi2 = q1 ? v3 : v2;
+                        return q2 ? hi2 : lo2;
+                    };
+                    const u32 s0 = sel(R0, R1, R2, R3), s1 = sel(R1, R2, R3, R4), s2 = sel(R2, R3, R4, R5),
+                              s3 = sel(R3, R4, R5, R6), s4 = sel(R4, R5, R6, R7);
+                    u32 xw[4];
+                    xw[0] = __builtin_amdgcn_alignbit(s1, s0, r5);
+                    xw[1] = __builtin_amdgcn_alignbit(s2, s1, r5);
+                    xw[2] = __builtin_amdgcn_alignbit(s3, s2, r5);
+                    xw[3] = __builtin_amdgcn_alignbit(s4, s3, r5);
+                    // the base behind the first k-mer (bits 2k .. 2k + 1 of the window): the second k-mer's last
+                    const u32 nbw = kb >= 96u ? xw[3] : xw[2];
+                    const u32 nb = (nbw >> (kb & 31u)) & 3u;
+                    const u32 x0 = xw[0] & km[0], x1 = xw[1] & km[1], x2 = xw[2] & km[2], x3 = xw[3] & km[3];
+                    // forward key: the window with the order of its bases reversed, right-aligned
+                    const u32 y0 = revpairs32(x3), y1 = revpairs32(x2), y2 = revpairs32(x1), y3 = revpairs32(x0);
+                    const u64 ylo = ((u64)y1 << 32) | y0, yhi = ((u64)y3 << 32) | y2;
+                    u64 flo = (ylo >> fs) | ((yhi << 1) << (63 - fs)), fhi = yhi >> fs;
+                    // reverse complement key: the complemented window
+                    u64 rlo = ((u64)(x1 ^ km[1]) << 32) | (x0 ^ km[0]), rhi = ((u64)(x3 ^ km[3]) << 32) | (x2 ^ km[2]);
 #pragma unroll
-            for (int e = 0; e < E; ++e) was[e] = 0u;
-            // One round: every active key tries its current entry.  Owners publish their high word before the
-            // readers of the same wave look at entries that hold their low word.
-#define SKM2_ROUND(TBL, TMASK)                                                                                         \
+                    for (int e = 0; e < E; ++e) {
+                        if (e) {   // roll both strands by one base
+                            fhi = ((fhi << 2) | (flo >> 62)) & kmhi;
+                            flo = (flo << 2) | nb;
+                            rlo = (rlo >> 2) | (rhi << 62);
+                            rhi = (rhi >> 2) | ((u64)(3u - nb) << tsh);
+                        }
+                        const bool fwd = fhi < rhi || (fhi == rhi && flo < rlo);
+                        klo[e] = fwd ? flo : rlo;
+                        khi[e] = fwd ? fhi : rhi;
+                        const u32 h = key2_hash(klo[e], khi[e]);
+                        slot_[e] = h >> (32 - HBITS);
+                        if ((u32)e < cnt && (R == 1 || (((h >> 4) & 0xffffu) * R) >> 16 == q)) act |= 1u << e;
+                    }
+                }
+                if (!__builtin_amdgcn_ballot_w64(act != 0)) continue;
+                u32* const mp = half ? tmhi : tmlo;
+                u32 was[E], f16[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) { was[e] = 0u; f16[e] = 0u; }
+                // One round: every active key tries its current entry.  Owners publish their high word before the
+                // readers of the same wave look at entries that hold their low word.
+#define SKM2_ROUND(KLO, KHI, MP, TMASK, SECOND)                                                                        \
     {                                                                                                                  \
         unsigned long long old[E];                                                                                     \
         _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                  \
-            old[e] = (act & (1u << e)) ? atomicCAS(&(TBL).klo[slot_[e]], EMPTY, (unsigned long long)klo[e]) : 0ull;    \
+            old[e] = (act & (1u << e)) ? atomicCAS(&(KLO)[slot_[e]], EMPTY, (unsigned long long)klo[e]) : 0ull;        \
         _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                  \
             if ((act & (1u << e)) && old[e] == EMPTY)                                                                  \
-                __hip_atomic_store(&(TBL).khi[slot_[e]], (unsigned long long)khi[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                __hip_atomic_store(&(KHI)[slot_[e]], (unsigned long long)khi[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
         _Pragma("unroll") for (int e = 0; e < E; ++e) {                                                                \
             if (act & (1u << e)) {                                                                                     \
                 bool hit = old[e] == EMPTY;                                                                            \
+                const bool fresh = hit;                                                                                \
                 if (!hit && old[e] == klo[e]) {                                                                        \
                     unsigned long long h2;                                                                             \
-                    do h2 = __hip_atomic_load(&(TBL).khi[slot_[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+                    do h2 = __hip_atomic_load(&(KHI)[slot_[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       \
                     while (h2 == EMPTY);                                                                               \
                     hit = h2 == khi[e];                                                                                \
                 }                                                                                                      \
                 if (hit) {                                                                                             \
-                    was[e] = atomicOr(((tag(e) & 32u) ? (TBL).mhi : (TBL).mlo) + slot_[e], 1u << (tag(e) & 31u));      \
+                    was[e] = atomicOr((MP) + slot_[e], bits);                                                          \
                     act &= ~(1u << e);                                                                                 \
+                    if (fresh) f16[e] = 0x8000u | (SECOND) | slot_[e];                                                 \
                 } else {                                                                                               \
                     slot_[e] = (slot_[e] + 1u) & (TMASK);                                                              \
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
     }
-            for (u32 round = 0; round < (u32)KH_HASH_ROUNDS && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(tbl, T - 1u)
-            if (__builtin_amdgcn_ballot_w64(act != 0)) {
+                for (u32 round = 0; round < 4u && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(tklo, tkhi, mp, T - 1u, 0u)
+                if (__builtin_amdgcn_ballot_w64(act != 0)) {
+                    u32* const mp2 = half ? omhi : omlo;
 #pragma unroll
-                for (int e = 0; e < E; ++e) { const u32 h = khash(e); slot_[e] = ((h ^ (h >> 15)) * 0x85EBCA77u) >> 25; }   // T2 = 128
-                for (u32 round = 0; round < T2 && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(ovf, T2 - 1u)
-                if (__builtin_amdgcn_ballot_w64(act != 0)) {   // second table full of other keys: on in the main table
+                    for (int e = 0; e < E; ++e) { const u32 h = key2_hash(klo[e], khi[e]); slot_[e] = ((h ^ (h >> 15)) * 0x85EBCA77u) >> 26; }   // T2 = 64
+                    for (u32 round = 0; round < 8u && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(oklo, okhi, mp2, T2 - 1u, 0x4000u)
+                    if (__builtin_amdgcn_ballot_w64(act != 0)) {   // a crowded second table: on in the main one
 #pragma unroll
-                    for (int e = 0; e < E; ++e) slot_[e] = ((khash(e) >> (32 - HBITS)) + (u32)KH_HASH_ROUNDS) & (T - 1u);
-                    for (u32 round = 0; round < T && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(tbl, T - 1u)
-                    if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                        for (int e = 0; e < E; ++e) slot_[e] = ((key2_hash(klo[e], khi[e]) >> (32 - HBITS)) + 4u) & (T - 1u);
+                        for (u32 round = 0; round < T && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(tklo, tkhi, mp, T - 1u, 0u)
+                        if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                    }
+                }
+#undef SKM2_ROUND
+                made[pass] = f16[0] | (f16[1] << 16);
+                {
+                    const u32 d = (was[0] | was[1]) & bits;
+                    if (d) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            u32 de = was[e] & bits;
+                            while (de) { atomicAdd(&dupc[half * 32u + (u32)__builtin_ctz(de)], 1u); de &= de - 1u; }
+                        }
+                    }
                 }
             }
-#undef SKM2_ROUND
+            __syncthreads();
+            // ---- all masks are final: every thread turns the entries it created into histogram bins
 #pragma unroll
-            for (int e = 0; e < E; ++e)
-                if ((was[e] >> (tag(e) & 31u)) & 1u) atomicAdd(&dupc[tag(e)], 1u);
-        }
-        __syncthreads();
-        // ---- every occupied entry is one distinct key of the slot: genome mask -> histogram bins
-        u32 ones = 0;   // keys that sit in exactly one group
-        for (u32 i = tid; i < T + T2; i += NT) {
-            const bool main_t = i < T;
-            const u32 j = main_t ? i : i - T;
-            const unsigned long long kl = main_t ? tbl.klo[j] : ovf.klo[j];
-            if (kl != EMPTY) {
-                const u64 emask = main_t ? (((u64)tbl.mhi[j] << 32) | tbl.mlo[j]) : (((u64)ovf.mhi[j] << 32) | ovf.mlo[j]);
-                const u32 ng = eval_mask(emask, ginfo[__ffsll((unsigned long long)emask) - 1]);
-                if (ng == 1u) ++ones;
-                else atomicAdd(&hstripe[(jb.abase + ng) * 8u + (lane & 7u)], 1u);
+            for (u32 pass = 0; pass < SKM2_PASSES; ++pass) {
+                if (!__builtin_amdgcn_ballot_w64(made[pass] != 0)) continue;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u32 f = (made[pass] >> (16 * e)) & 0xffffu;
+                    if (f & 0x8000u) {
+                        const u32 at = f & 0x3fffu;
+                        const bool second = f & 0x4000u;
+                        if (eval_mask((second ? omlo : tmlo)[at], (second ? omhi : tmhi)[at])) ++ones;
+                    }
+                }
             }
+            if (__builtin_amdgcn_ballot_w64(ones != 0)) {
+                ones = wave_scan_add(ones);
+                if (lane == KH_WAVE - 1) atomicAdd(&hstripe[(jb.abase + 1u) << sshift], ones);
+            }
+            if (q + 1 < R) __syncthreads();
         }
-        ones = wave_scan_add(ones);
-        if (lane == KH_WAVE - 1 && ones) atomicAdd(&hstripe[(jb.abase + 1u) * 8u], ones);
-        __syncthreads();
+        nrec = nrec_next;
+        nrec_next = nrec_after;
     }
+    __syncthreads();
+    tid = tid0;
     unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
     for (u32 i = tid; i < nbins; i += NT) {
         u32 v = 0;
-#pragma unroll
-        for (u32 j = 0; j < 8; ++j) v += hstripe[i * 8u + j];
+        for (u32 j = 0; j <= smask; ++j) v += hstripe[(i << sshift) + j];
         if (v) atomicAdd(&rep[i], (unsigned long long)v);
     }
     if (tid < (u32)KH_TAG_MAX_OPS && dupc[tid]) atomicAdd(&jb.dup[tid], (unsigned long long)dupc[tid]);
+    if (tid == 0) {
+        if (st_full > T) atomicMax(jb.ctl + 1, st_full);
+        atomicAdd(jb.ctl + 3, st_exp);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -597,8 +681,8 @@ void kh_launch_skm2_regroup(const KhSkmJob& job, hipStream_t st) {
     skm2_allow_lds(k_skm2_regroup, lds);
     hipLaunchKernelGGL(k_skm2_regroup, dim3(job.nb1), dim3(SKM_RG_NT), lds, st, job);
 }
-void kh_launch_skm2_union(const KhSkmJob& job, u32 cs, hipStream_t st) {
+void kh_launch_skm2_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st) {
     const size_t lds = kh_skm2_union_lds_bytes(job.nbins);
     skm2_allow_lds(k_skm2_union, lds);
-    hipLaunchKernelGGL(k_skm2_union, dim3(job.nslots), dim3(SKM2_UNT), lds, st, job, cs);
+    hipLaunchKernelGGL(k_skm2_union, dim3(grid), dim3(SKM2_UNT), lds, st, job, cs);
 }
