@@ -229,10 +229,12 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_stale": traffic_stale,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)}
-    # The dominant kernel of the super-k-mer form is bound by vector instruction issue, not by HBM: when the SQ
-    # counter file was collected on exactly these sources (tools/pmc_sq.sh), report its wave instructions per
-    # second against the chip's issue rate (256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at the
-    # 2.4 GHz peak clock; MI355X_MICROARCH.md, instruction issue costs).
+    # The dominant kernel of the super-k-mer form is bound by vector instruction issue and LDS round trips, not by
+    # HBM: when the SQ counter file was collected on exactly these sources (tools/pmc_sq.sh), report its wave
+    # instructions per second against the chip's MEASURED issue rate for the integer instructions these kernels are
+    # made of (tools/micro/valu_issue.hip, profiles/r03_valu_issue.txt: 595 G wave-instructions/s for VOP3 / VOP1 /
+    # 64-bit forms at 8 waves per SIMD on every CU = one per 4.1 cycles per SIMD; plain v_add_u32 / v_xor_b32 reach
+    # 950-1050 G/s, which this mix cannot).
     issue = None
     spath = os.path.join(ROOT, "profiles", "sq_counters.json")
     if os.path.exists(spath):
@@ -240,7 +242,7 @@ def main():
             sj = json.load(open(spath))
             if sj.get("_source_sha") == source_hash() and hot in sj and avg_ms > 0:
                 valu = sj[hot].get("SQ_INSTS_VALU", 0)
-                peak = 256 * 4 * 2.4e9 / 4
+                peak = 595e9
                 issue = {"bound": "valu_issue", "kernel": hot, "wave_instructions_per_launch": int(valu),
                          "achieved": round(valu / (avg_ms * 1e-3) / 1e9, 1), "peak": round(peak / 1e9, 1),
                          "unit": "G wave-instr/s", "frac": round(valu / (avg_ms * 1e-3) / peak, 4),

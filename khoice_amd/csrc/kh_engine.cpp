@@ -1632,7 +1632,16 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         if (c2 <= (double)max_cap2 || mean <= 256) break;
         mean = std::max<u32>(256, (u32)((double)mean * (double)max_cap2 / c2 * 0.98));
     }
-    const u64 nslots64 = rec_out && rec_out->force_slots ? rec_out->force_slots : std::max<u64>(1, (total_pos + mean - 1) / mean);
+    u64 nslots64 = rec_out && rec_out->force_slots ? rec_out->force_slots : std::max<u64>(1, (total_pos + mean - 1) / mean);
+    // One-word keys a little above 256 x 512 slots (short windows on the headline shape: k = 20): 512 coarse buckets
+    // double the scatter's cursors and LDS (k = 20: scatter 2.3 ms against 1.0 at k = 21).  Since a slot's region may
+    // overflow (side list, k_skm_big) its slack can be cut instead: stay at 256 x 512 slots with slack down to 1.4.
+    if (!two && !(rec_out && rec_out->force_slots) && nslots64 > (u64)KH_SKM_MAX_COARSE * KH_SKM_MAX_FINE) {
+        const u64 lim = (u64)KH_SKM_MAX_COARSE * KH_SKM_MAX_FINE;
+        const double per_slot = (double)total_pos * per_kmer / (double)lim;
+        const double s2 = ((double)max_cap2 - 112.0) / per_slot;
+        if (s2 >= 1.4) { nslots64 = lim; slack2 = std::min(slack2, s2); }
+    }
     // coarse buckets: 256 keep the scatter's runs long; inputs past 256 x 512 slots (> 400 M k-mers) take 512
     const u32 max_coarse = (two || nslots64 > (u64)KH_SKM_MAX_COARSE * KH_SKM_MAX_FINE) ? KH_SKM2_MAX_COARSE : KH_SKM_MAX_COARSE;
     if (nslots64 > (u64)max_coarse * (two ? KH_SKM2_MAX_FINE : KH_SKM_MAX_FINE)) return KH_OK;

@@ -15,7 +15,9 @@ CLASS = {"k_extract<1, false>": "extract_hist", "k_extract<2, false>": "extract_
          "k_extract<2, true>": "extract_scatter", "k_bucket_sort_rle": "bucket_sort_rle",
          "k_setop": "setop", "k_range_bounds": "range_bounds", "k_union_tagged": "union_tagged",
          "k_union_hash": "union_tagged", "k_grid_bucket": "bucket_sort_rle", "k_grid_oversize": "grid_oversize",
-         "k_skm_scatter": "skm_scatter", "k_skm_regroup": "skm_regroup", "k_skm_union": "skm_union"}
+         "k_skm_scatter": "skm_scatter", "k_skm_regroup": "skm_regroup", "k_skm_union": "skm_union",
+         "k_skm2_scatter": "skm_scatter", "k_skm2_regroup": "skm_regroup", "k_skm2_union": "skm_union",
+         "k_skm_pack": "skm_pack", "k_skm_phased": "skm_phased", "k_skm_big": "skm_big"}
 
 
 def cls(name):
