@@ -1689,7 +1689,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     seq_bytes += 256;
     const u32 ntiles = (u32)tiles.size();
     // the union is persistent (as many workgroups as fit the chip, each with a histogram of its own)
-    const u32 ugrid = std::min<u32>(nslots, (two ? 2u : kh_skm_union_per_cu(table)) * (u32)std::max(1, c->cus));
+    const u32 ugrid = std::min<u32>(nslots, (two ? kh_skm2_union_per_cu() : kh_skm_union_per_cu(table)) * (u32)std::max(1, c->cus));
     const u32 reps = ugrid;
     const size_t hist_words = (size_t)reps * nbins;
     // workspace: [hist][ctl: 8 u32][inst: nseq u64][dup: 64 u64][cur1: nb1 u32][cur2: nslots u32] (zeroed) [ginfo: 64 u32]

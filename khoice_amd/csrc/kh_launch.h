@@ -208,6 +208,7 @@ constexpr u32 KH_SKM2_MAX_FINE = 1024;    // slots per coarse bucket with two-wo
 bool kh_skm2_supports_w(u32 w);
 u32 kh_skm2_max_cap2();
 u32 kh_skm2_table();
+u32 kh_skm2_union_per_cu();   // workgroups of the two-word union that fit a CU
 size_t kh_skm2_scatter_lds_bytes(u32 nb1);
 size_t kh_skm2_regroup_lds_bytes(u32 S);
 size_t kh_skm2_union_lds_bytes(u32 nbins);

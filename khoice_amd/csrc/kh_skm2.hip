@@ -310,11 +310,23 @@ __global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm2_regroup(const KhSkmJob jb
 // expanded; chunks of two consecutive k-mers per thread, the second by rolling both strands; every thread turns the
 // entries it created into histogram bins once the masks are final.
 // ------------------------------------------------------------------------------------------
-constexpr u32 SKM2_UNT = 1024, SKM2_UT = 2048, SKM2_UT2 = 64, SKM2_HBITS = 11;
+// Geometry: 512 threads and a table of 1792 entries (24 bytes each) = 52 KB of LDS: THREE workgroups per CU.  The kernel
+// is bound by the chain of LDS round trips per slot, not by what a slot's threads do: 1024 threads x 2048 entries (two
+// per CU) and 512 x 2048 (two per CU) both took 3.07-3.11 ms at k = 41 — a slot of ~95 records and ~350 chunks leaves
+// most of 1024 threads without work — so what counts is how many slots a CU has in flight.
+#ifndef KH_TUNE_SKM2_UNT
+#define KH_TUNE_SKM2_UNT 512
+#endif
+#ifndef KH_TUNE_SKM2_UT
+#define KH_TUNE_SKM2_UT 1792
+#endif
+constexpr u32 SKM2_UNT = KH_TUNE_SKM2_UNT, SKM2_UT = KH_TUNE_SKM2_UT, SKM2_UT2 = 32;   // (the table need not be a power of two)
 constexpr u32 SKM2_UE = 2;                         // k-mers per chunk
 constexpr u32 SKM2_OB = 5;                         // bits of a chunk's number inside its record (n <= 63)
-constexpr u32 SKM2_MAXREC = 512;                   // records of a slot: staged in the low key plane (16 KB)
-constexpr u32 SKM2_PASSES = 3;
+constexpr u32 SKM2_STAGE = SKM2_UT * 8 / 32;       // 32-byte records the low key plane holds
+constexpr u32 SKM2_MAXREC = SKM2_STAGE < SKM2_UNT ? SKM2_STAGE : SKM2_UNT;   // records of a slot: one per thread, staged in the low key plane
+constexpr u32 SKM2_DD = SKM2_UT * 2;               // entries of the set of record contents (the high key plane)
+constexpr u32 SKM2_PASSES = 4;
 constexpr u32 SKM2_MAXCH = SKM2_PASSES * SKM2_UNT; // chunks of a slot after the merge
 constexpr u32 SKM2_HSTRIPE_WORDS = 288;
 size_t kh_skm2_union_lds_bytes(u32) {
@@ -323,12 +335,14 @@ size_t kh_skm2_union_lds_bytes(u32) {
 }
 u32 kh_skm2_max_cap2() { return SKM2_MAXREC; }
 u32 kh_skm2_table() { return SKM2_UT; }
+u32 kh_skm2_union_per_cu() { return kh_skm2_union_lds_bytes(0) * 3 <= 160 * 1024 && SKM2_UNT * 3 <= 2048 ? 3u : 2u; }
 
 __device__ __forceinline__ u32 key2_hash(u64 lo, u64 hi) { return ((u32)lo ^ (u32)(lo >> 32) ^ (u32)hi ^ (u32)(hi >> 32)) * 0x9E3779B1u; }
 
-__global__ __launch_bounds__(SKM2_UNT, 8) void k_skm2_union(const KhSkmJob jb, u32 cs) {
+__global__ __launch_bounds__(SKM2_UNT, SKM2_UNT == 1024 ? 8 : 6) void k_skm2_union(const KhSkmJob jb, u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
-    constexpr u32 NT = SKM2_UNT, T = SKM2_UT, T2 = SKM2_UT2, HBITS = SKM2_HBITS, NW = NT / 64;
+    constexpr u32 NT = SKM2_UNT, T = SKM2_UT, T2 = SKM2_UT2, NW = NT / 64;
+    static_assert((T2 & (T2 - 1)) == 0 && T % 4 == 0, "second table: a power of two");
     constexpr int E = (int)SKM2_UE;
     constexpr u64 EMPTY = ~0ull;   // never the low word of a canonical key for k <= 63 (see the head of the file)
     u8* p = lds_raw;
@@ -349,7 +363,7 @@ __global__ __launch_bounds__(SKM2_UNT, 8) void k_skm2_union(const KhSkmJob jb, u
     // the records are staged in the low key plane (32 bytes each), the set of their contents is the high key plane
     uint4* stage = reinterpret_cast<uint4*>(tklo);
     u32* dd = reinterpret_cast<u32*>(tkhi);   // [T * 2] record number + 1
-    constexpr u32 DD = 2 * T;
+    constexpr u32 DD = SKM2_DD;
     const u32 tid0 = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     u32 tid = tid0, lane = lane_id();
     const u32 nbins = jb.nbins, cap2 = jb.cap2, nslots = jb.nslots, stride = gridDim.x;
@@ -363,13 +377,12 @@ __global__ __launch_bounds__(SKM2_UNT, 8) void k_skm2_union(const KhSkmJob jb, u
     const u64 kmhi = ((u64)km[3] << 32) | km[2];
     const u32 fs = 128u - kb;           // 2 .. 62
     const u32 tsh = kb - 2u - 64u;      // where the last base sits in the high word: 0 .. 60
-    auto clear_keys = [&]() {   // key words all ones (low: empty, high: not yet published)
+    auto clear_keys = [&]() {   // key words all ones (low: empty, high: not yet published): T * 16 bytes
         uint4* k4 = reinterpret_cast<uint4*>(tklo);
-#pragma unroll
-        for (u32 e = 0; e < T / NT; ++e) k4[e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        for (u32 i = tid; i < T; i += NT) k4[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
     };
     auto clear_masks = [&]() {
-        reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);   // (both mask planes: T * 8 bytes = NT uint4)
+        for (u32 i = tid; i < T / 2; i += NT) reinterpret_cast<uint4*>(tmlo)[i] = make_uint4(0u, 0u, 0u, 0u);   // (both mask planes: T * 8 bytes)
         unsigned long long e0 = EMPTY;
         asm volatile("" : "+v"(e0));
         if (tid < T2) { oklo[tid] = e0; okhi[tid] = e0; omlo[tid] = 0u; omhi[tid] = 0u; }
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(SKM2_UNT, 8) void k_skm2_union(const KhSkmJob jb, u
         {
             u32 z = 0;
             asm volatile("" : "+v"(z));
-            reinterpret_cast<uint4*>(dd)[tid] = make_uint4(z, z, z, z);   // DD = 4096 entries = NT uint4
+            for (u32 i = tid; i < DD / 4; i += NT) reinterpret_cast<uint4*>(dd)[i] = make_uint4(z, z, z, z);
         }
         if (tid < nrec) {
             nj = rec2_n(b3);
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(SKM2_UNT, 8) void k_skm2_union(const KhSkmJob jb, u
                     b2 * 0xFD7046C5u ^ (b3 & ~(63u << 20)) * 0xB55A4F09u;
             h ^= h >> 15;
             h *= 0x2C1B3C6Du;
-            u32 hp = h >> 20;   // DD = 4096
+            u32 hp = (u32)(((u64)h * DD) >> 32);
             const u32 nch = (nj + (u32)E - 1u) / (u32)E;
             bool pend = nj != 0, won = false;
             while (__builtin_amdgcn_ballot_w64(pend)) {
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(SKM2_UNT, 8) void k_skm2_union(const KhSkmJob jb, u
                             const u32 was = atomicOr(&rmask[old - 1u], bit);
                             if (was & bit) atomicAdd(&dupc[tg], nj);
                             pend = false;
-                        } else hp = (hp + 1u) & (DD - 1u);
+                        } else hp = hp + 1u == DD ? 0u : hp + 1u;
                     }
                 }
             }
@@ -549,7 +562,7 @@ __global__ __launch_bounds__(SKM2_UNT, 8) void k_skm2_union(const KhSkmJob jb, u
                         klo[e] = fwd ? flo : rlo;
                         khi[e] = fwd ? fhi : rhi;
                         const u32 h = key2_hash(klo[e], khi[e]);
-                        slot_[e] = h >> (32 - HBITS);
+                        slot_[e] = (u32)(((u64)h * T) >> 32);
                         if ((u32)e < cnt && (R == 1 || (((h >> 4) & 0xffffu) * R) >> 16 == q)) act |= 1u << e;
                     }
                 }
@@ -560,7 +573,7 @@ __global__ __launch_bounds__(SKM2_UNT, 8) void k_skm2_union(const KhSkmJob jb, u
                 for (int e = 0; e < E; ++e) { was[e] = 0u; f16[e] = 0u; }
                 // One round: every active key tries its current entry.  Owners publish their high word before the
                 // readers of the same wave look at entries that hold their low word.
-#define SKM2_ROUND(KLO, KHI, MP, TMASK, SECOND)                                                                        \
+#define SKM2_ROUND(KLO, KHI, MP, TSIZE, SECOND)                                                                        \
     {                                                                                                                  \
         unsigned long long old[E];                                                                                     \
         _Pragma("unroll") for (int e = 0; e < E; ++e)                                                                  \
@@ -583,21 +596,21 @@ __global__ __launch_bounds__(SKM2_UNT, 8) void k_skm2_union(const KhSkmJob jb, u
                     act &= ~(1u << e);                                                                                 \
                     if (fresh) f16[e] = 0x8000u | (SECOND) | slot_[e];                                                 \
                 } else {                                                                                               \
-                    slot_[e] = (slot_[e] + 1u) & (TMASK);                                                              \
+                    slot_[e] = slot_[e] + 1u == (TSIZE) ? 0u : slot_[e] + 1u;                                          \
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
     }
-                for (u32 round = 0; round < 4u && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(tklo, tkhi, mp, T - 1u, 0u)
+                for (u32 round = 0; round < 4u && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(tklo, tkhi, mp, T, 0u)
                 if (__builtin_amdgcn_ballot_w64(act != 0)) {
                     u32* const mp2 = half ? omhi : omlo;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) { const u32 h = key2_hash(klo[e], khi[e]); slot_[e] = ((h ^ (h >> 15)) * 0x85EBCA77u) >> 26; }   // T2 = 64
-                    for (u32 round = 0; round < 8u && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(oklo, okhi, mp2, T2 - 1u, 0x4000u)
+                    for (int e = 0; e < E; ++e) { const u32 h = key2_hash(klo[e], khi[e]); slot_[e] = ((h ^ (h >> 15)) * 0x85EBCA77u) >> 27; }   // T2 = 32
+                    for (u32 round = 0; round < 8u && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(oklo, okhi, mp2, T2, 0x4000u)
                     if (__builtin_amdgcn_ballot_w64(act != 0)) {   // a crowded second table: on in the main one
 #pragma unroll
-                        for (int e = 0; e < E; ++e) slot_[e] = ((key2_hash(klo[e], khi[e]) >> (32 - HBITS)) + 4u) & (T - 1u);
-                        for (u32 round = 0; round < T && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(tklo, tkhi, mp, T - 1u, 0u)
+                        for (int e = 0; e < E; ++e) { const u32 x = (u32)(((u64)key2_hash(klo[e], khi[e]) * T) >> 32) + 4u; slot_[e] = x >= T ? x - T : x; }
+                        for (u32 round = 0; round < T && __builtin_amdgcn_ballot_w64(act != 0); ++round) SKM2_ROUND(tklo, tkhi, mp, T, 0u)
                         if (__builtin_amdgcn_ballot_w64(act != 0) && lane == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
                     }
                 }
