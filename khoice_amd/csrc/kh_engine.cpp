@@ -1606,7 +1606,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     // entries of the union's hash set (one-word keys): 4096 with 1024 threads (two workgroups per CU) or 2048 with 512
     // (four per CU, half-size slots)
     u32 table = 4096;
-    if (const char* e = getenv("KHOICE_SKM_TABLE")) table = atoi(e) == 2048 ? 2048u : 4096u;
+    if (const char* e = getenv("KHOICE_SKM_TABLE")) table = atoi(e) == 2048 ? 2048u : (atoi(e) == 2560 ? 2560u : 4096u);
     u32 mean;
     double clump = 1.0;   // instances that land in a slot together
     {

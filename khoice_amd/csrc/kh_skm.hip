@@ -376,19 +376,20 @@ constexpr u32 SKM_OB = SKM_UE == 2 ? 4 : 3;           // bits of a chunk's numbe
 constexpr u32 SKM_PASSES = SKM_UE == 2 ? 3 : 2;       // chunks of a slot: at most SKM_PASSES per thread
 constexpr u32 SKM_HSTRIPE_WORDS = 288;                // histogram copies in LDS: 4 / 2 / 1 per bin for <= 72 / 144 / 255 bins
 template <u32 NT, u32 T> struct SkmUnionGeo {
-    static constexpr u32 T2 = T / 32;                 // second table
+    static constexpr u32 T2 = T >= 4096 ? 128 : 64;   // second table (a power of two; the main one need not be)
     static constexpr u32 MAXREC = NT;                 // records of a slot (cap2 <= this): one per thread
     static constexpr u32 MAXCH = SKM_PASSES * NT;     // chunks of a slot (after the merge of identical records)
-    static constexpr u32 HBITS = T == 4096 ? 12 : (T == 2048 ? 11 : 10);
     static constexpr size_t LDS = (size_t)T * 16 + (size_t)T2 * 16 + 1024 + 128 + 256 + (size_t)SKM_HSTRIPE_WORDS * 4 +
                                   (size_t)MAXCH * 2 + (size_t)MAXREC * 4;
     static_assert(MAXREC * 16 <= T * 4, "records are staged in the first half of the key plane");
-    static_assert(T2 <= NT && T / 4 <= NT, "clears are one store per thread");
+    static_assert(T2 <= NT && T % 4 == 0, "table planes are cleared 16 bytes at a time");
 };
-u32 kh_skm_union_threads(u32 table) { return table == 2048 ? 512u : 1024u; }
+u32 kh_skm_union_threads(u32 table) { return table == 2048 ? 512u : (table == 2560 ? 640u : 1024u); }
 u32 kh_skm_union_max_cap2(u32 table) { return kh_skm_union_threads(table); }
-u32 kh_skm_union_per_cu(u32 table) { return table == 2048 ? 3u : 2u; }
-size_t kh_skm_union_lds_bytes(u32 table) { return table == 2048 ? SkmUnionGeo<512, 2048>::LDS : SkmUnionGeo<1024, 4096>::LDS; }
+u32 kh_skm_union_per_cu(u32 table) { return table == 4096 ? 2u : 3u; }
+size_t kh_skm_union_lds_bytes(u32 table) {
+    return table == 2048 ? SkmUnionGeo<512, 2048>::LDS : (table == 2560 ? SkmUnionGeo<640, 2560>::LDS : SkmUnionGeo<1024, 4096>::LDS);
+}
 
 __device__ __forceinline__ u32 key_hash2(u32 lo, u32 hi) { return (lo ^ hi) * 0x9E3779B1u; }
 
@@ -412,7 +413,8 @@ template <u32 NT, u32 T>
 __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     using G = SkmUnionGeo<NT, T>;
-    constexpr u32 T2 = G::T2, HBITS = G::HBITS, NW = NT / 64;
+    constexpr u32 T2 = G::T2, NW = NT / 64;
+    constexpr u32 T2SH = T2 == 128 ? 25 : 26;   // 32 - log2(T2)
     constexpr int E = (int)SKM_UE;
     constexpr u64 EMPTY = ~0ull;   // never a canonical key: the reverse complement of the all-T k-mer is 0
     // Table planes: keys (8-byte stride), low and high halves of the genome masks (4-byte stride).
@@ -441,14 +443,10 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
     const u32 sshift = nbins <= 72u ? 2u : (nbins <= 144u ? 1u : 0u), smask = (1u << sshift) - 1u;
     auto clear_keys = [&]() {
         uint4* k4 = reinterpret_cast<uint4*>(tkey);
-#pragma unroll
-        for (u32 e = 0; e < T / 2 / NT; ++e) k4[e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        for (u32 i = tid; i < T / 2; i += NT) k4[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
     };
     auto clear_masks = [&]() {
-        if (tid < T / 4) {
-            reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);
-            reinterpret_cast<uint4*>(tmhi)[tid] = make_uint4(0u, 0u, 0u, 0u);
-        }
+        for (u32 i = tid; i < T / 2; i += NT) reinterpret_cast<uint4*>(tmlo)[i] = make_uint4(0u, 0u, 0u, 0u);   // (both mask planes)
         unsigned long long e0 = EMPTY;   // (opaque, as `emptyv` below)
         asm volatile("" : "+v"(e0));
         if (tid < T2) { okey[tid] = e0; omlo[tid] = 0u; omhi[tid] = 0u; }
@@ -526,7 +524,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
         {
             u32 z = 0;   // (opaque: a zero kept in four registers across the loop was spilled)
             asm volatile("" : "+v"(z));
-            if (tid < T / 4) reinterpret_cast<uint4*>(dd)[tid] = make_uint4(z, z, z, z);
+            for (u32 i = tid; i < T / 4; i += NT) reinterpret_cast<uint4*>(dd)[i] = make_uint4(z, z, z, z);
         }
         if (tid < nrec) {
             nj = rr.w >> 27;
@@ -544,7 +542,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
             u32 h = rx * 0x9E3779B1u ^ ry * 0x85EBCA77u ^ rz * 0xC2B2AE3Du ^ (rw & ~(63u << 21)) * 0x27D4EB2Fu;
             h ^= h >> 15;
             h *= 0x2C1B3C6Du;
-            u32 hp = h >> (32 - HBITS);
+            u32 hp = (u32)(((u64)h * T) >> 32);
             const u32 nch = (nj + (u32)E - 1u) / (u32)E;
             bool pend = nj != 0, won = false;
             while (__builtin_amdgcn_ballot_w64(pend)) {
@@ -562,7 +560,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
                             if (was & bit) atomicAdd(&dupc[tg], nj);   // a second copy inside one genome: nj repeats
                             pend = false;
                         } else {
-                            hp = (hp + 1u) & (T - 1u);
+                            hp = hp + 1u == T ? 0u : hp + 1u;
                         }
                     }
                 }
@@ -609,9 +607,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
         SKM_MARK("owner_done");
         SKM_USTAMP(4);
         const u32 R = (N + T - 1) / T;   // key subsets handled one after the other (1 unless the slot is overfull)
-        // Chunks are taken by the first C threads of a ROTATED numbering of the waves (a slot with fewer chunks than
-        // threads keeps different SIMDs busy from slot to slot).
-        const u32 ctid = (((wid + ((slot * 2654435761u) >> 16)) & (NW - 1u)) << 6) | lane;
+        const u32 ctid = tid;   // (a rotated numbering of the waves — other SIMDs busy from slot to slot — changed nothing)
         for (u32 q = 0; q < R; ++q) {
             if (q) { clear_keys(); clear_masks(); __syncthreads(); }
             unsigned long long emptyv = EMPTY;   // (opaque: made here, or the compiler keeps the constant in two VGPRs across the loop and spills it)
@@ -659,7 +655,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
                         const u32 cl = fwd ? fl : rl, ch = fwd ? fh : rh;
                         const u32 h = key_hash2(cl, ch);
                         kreg[e] = ((u64)ch << 32) | cl;
-                        slot_[e] = h >> (32 - HBITS);
+                        slot_[e] = (u32)(((u64)h * T) >> 32);
                         if (R != 1 && (u32)e < cnt && (((h >> 4) & 0xffffu) * R) >> 16 == q) act |= 1u << e;
                     }
                     if (R == 1) act = (1u << cnt) - 1u;
@@ -689,7 +685,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
                                 act &= ~(1u << e);
                                 if (fresh) mk |= 1u << e;
                             } else {
-                                slot_[e] = (slot_[e] + 1u) & (T - 1u);
+                                slot_[e] = slot_[e] + 1u == T ? 0u : slot_[e] + 1u;
                             }
                         }
                     }
@@ -709,7 +705,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
                         if (es == (u32)e) K = kreg[e];
                     const u32 H = key_hash2((u32)K, (u32)(K >> 32));
                     // level 1: second table, 2: main table, unbounded
-                    u32 S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> (32 - HBITS + 5), probes = 0, level = 1, tmask = T2 - 1u;   // T2 = T / 32
+                    u32 S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> T2SH, probes = 0, level = 1;
                     bool mine = have_one;
                     u32 where = 0;
                     while (__builtin_amdgcn_ballot_w64(mine)) {
@@ -725,13 +721,14 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
                             } else {
                                 ++probes;
                                 if (level == 1 && probes >= 8u) {   // a crowded second table: on in the main one
-                                    level = 2; probes = 0; tmask = T - 1u;
-                                    S = ((H >> (32 - HBITS)) + (u32)KH_TUNE_SKM_FULL_ROUNDS) & (T - 1u);
+                                    level = 2; probes = 0;
+                                    S = (u32)(((u64)H * T) >> 32) + (u32)KH_TUNE_SKM_FULL_ROUNDS;
+                                    S = S >= T ? S - T : S;
                                 } else if (level == 2 && probes >= T) {
                                     atomicOr(jb.ctl, KH_ERR_CAPACITY);   // cannot happen: a round holds at most T keys
                                     mine = false;
                                 } else {
-                                    S = (S + 1u) & tmask;
+                                    S = level == 1 ? ((S + 1u) & (T2 - 1u)) : (S + 1u == T ? 0u : S + 1u);
                                 }
                             }
                         }
@@ -1351,6 +1348,9 @@ void kh_launch_skm_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st) 
     if (job.table == 2048) {
         skm_allow_lds(k_skm_union<512, 2048>, lds);
         hipLaunchKernelGGL((k_skm_union<512, 2048>), dim3(grid), dim3(512), lds, st, job, cs);
+    } else if (job.table == 2560) {
+        skm_allow_lds(k_skm_union<640, 2560>, lds);
+        hipLaunchKernelGGL((k_skm_union<640, 2560>), dim3(grid), dim3(640), lds, st, job, cs);
     } else {
         skm_allow_lds(k_skm_union<1024, 4096>, lds);
         hipLaunchKernelGGL((k_skm_union<1024, 4096>), dim3(grid), dim3(1024), lds, st, job, cs);

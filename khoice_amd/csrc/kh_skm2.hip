@@ -503,7 +503,7 @@ __global__ __launch_bounds__(SKM2_UNT, SKM2_UNT == 1024 ? 8 : 6) void k_skm2_uni
         __syncthreads();
         if (tid == 0) scratch[0] = 0;
         const u32 R = (N + T - 1) / T;
-        const u32 ctid = (((wid + ((slot * 2654435761u) >> 16)) & (NW - 1u)) << 6) | lane;
+        const u32 ctid = tid;
         for (u32 q = 0; q < R; ++q) {
             if (q) { clear_keys(); clear_masks(); __syncthreads(); }
             u32 made[SKM2_PASSES];
