@@ -1642,6 +1642,14 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         const double s2 = ((double)max_cap2 - 112.0) / per_slot;
         if (s2 >= 1.4) { nslots64 = lim; slack2 = std::min(slack2, s2); }
     }
+    // two-word keys a little above 512 x 1024 slots (configs[2] at k = 41, the pass by group over 500 M positions):
+    // the same cut, up to what the union's table takes in one go on average
+    if (two && !(rec_out && rec_out->force_slots) && nslots64 > (u64)KH_SKM2_MAX_COARSE * KH_SKM2_MAX_FINE) {
+        const u64 lim = (u64)KH_SKM2_MAX_COARSE * KH_SKM2_MAX_FINE;
+        const double per_slot = (double)total_pos * per_kmer / (double)lim;
+        const double s2 = ((double)max_cap2 - 112.0) / per_slot;
+        if (s2 >= 1.4 && (double)total_pos / (double)lim <= 0.75 * (double)kh_skm2_table()) { nslots64 = lim; slack2 = std::min(slack2, s2); }
+    }
     // coarse buckets: 256 keep the scatter's runs long; inputs past 256 x 512 slots (> 400 M k-mers) take 512
     const u32 max_coarse = (two || nslots64 > (u64)KH_SKM_MAX_COARSE * KH_SKM_MAX_FINE) ? KH_SKM2_MAX_COARSE : KH_SKM_MAX_COARSE;
     if (nslots64 > (u64)max_coarse * (two ? KH_SKM2_MAX_FINE : KH_SKM_MAX_FINE)) return KH_OK;
@@ -1700,7 +1708,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
                  ws_bytes = off_tiles + sizeof(KhTile) * (size_t)std::max<u32>(1, ntiles);   // [ginfo .. tiles]: one upload
     Tmp d_seq, d_ws, d_reg1, d_reg2, d_spill;
     // one-word keys: what a slot's region cannot hold goes to a side list, the slot to a kernel of its own
-    const u32 spill_cap = two ? 0u : 1u << 17, big_cap = two ? 0u : 4096u;
+    const u32 spill_cap = 1u << 18, big_cap = 4096u;
     bool need_pack = false;
     for (int i = 0; i < nseq; ++i)
         if (!(on_device && (reinterpret_cast<uintptr_t>(seqs[perm[i]]) & 15) == 0)) need_pack = true;
@@ -1708,7 +1716,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     TMP_ALLOC(d_ws, c, ws_bytes);
     TMP_ALLOC(d_reg1, c, reg1_bytes);
     TMP_ALLOC(d_reg2, c, reg2_bytes);
-    if (spill_cap) TMP_ALLOC(d_spill, c, (size_t)spill_cap * 20 + (size_t)big_cap * 4);
+    if (spill_cap) TMP_ALLOC(d_spill, c, (size_t)spill_cap * (rec_bytes + 4) + (size_t)big_cap * 4);
     struct PinG { kh_ctx* c; void* p = nullptr; size_t n = 0; ~PinG() { if (p) c->pin_release(p, n); } } pin{c};
     // pinned staging: [segs][tiles][ginfo] up, [hist .. dup] down
     const size_t up_bytes = ws_bytes - off_ginfo;   // the upload, laid out as on the device
@@ -1765,8 +1773,8 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     job.nbins = nbins; job.abase = abase; job.reps = reps; job.nops = by_group ? (u32)ngroups : (u32)nseq;
     job.table = table;
     job.spill_rec = spill_cap ? d_spill.as<uint4>() : nullptr;
-    job.spill_slot = spill_cap ? reinterpret_cast<u32*>(d_spill.as<u8>() + (size_t)spill_cap * 16) : nullptr;
-    job.big_list = spill_cap ? reinterpret_cast<u32*>(d_spill.as<u8>() + (size_t)spill_cap * 20) : nullptr;
+    job.spill_slot = spill_cap ? reinterpret_cast<u32*>(d_spill.as<u8>() + (size_t)spill_cap * rec_bytes) : nullptr;
+    job.big_list = spill_cap ? reinterpret_cast<u32*>(d_spill.as<u8>() + (size_t)spill_cap * (rec_bytes + 4)) : nullptr;
     job.spill_cap = spill_cap;
     job.big_cap = big_cap;
 #ifdef KH_STAMPS
@@ -1830,21 +1838,22 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         for (u32 v : h1) { t1 += v; m1 = std::max(m1, v); }
         for (u32 v : h2) { t2 += v; m2 = std::max(m2, v); }
         fprintf(stderr, "[skm] k=%d m=%d w=%u nmax=%u positions=%llu records=%llu (%.2f k-mers each) nb1=%u S=%u nslots=%u | "
-                        "coarse: mean %.0f max %u cap %u | slot: mean %.1f max %u cap %u | tiles %u x %u | expanded: %u k-mers\n",
+                        "coarse: mean %.0f max %u cap %u | slot: mean %.1f max %u cap %u | tiles %u x %u | expanded: %u k-mers | errors %u spilled %u overfull slots %u\n",
                 k, m, w, nmax, (unsigned long long)total_pos, (unsigned long long)t1, (double)total_pos / std::max<u64>(1, t1),
-                nb1, S, nslots, (double)t1 / nb1, m1, cap1, (double)t2 / nslots, m2, cap2, ntiles, tile_pos, hc[3]);
+                nb1, S, nslots, (double)t1 / nb1, m1, cap1, (double)t2 / nslots, m2, cap2, ntiles, tile_pos, hc[3], hc[0], hc[5], hc[6]);
     }
     HIPCHK(hipMemcpyAsync(h_down, wsp, down_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const u64* h_hist = reinterpret_cast<const u64*>(h_down);
     const u32* h_ctl = reinterpret_cast<const u32*>(h_down + off_ctl);
-    if (!two && h_ctl[6] && !(h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER))) {
+    if (h_ctl[6] && !(h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER))) {
         // overfull slots (skewed input: a minimizer shared by far more k-mers than a hash predicts): the union left
         // them out; one workgroup each now, and the read-back again — only these slots are done twice, not the call
         if (h_ctl[5] > spill_cap || h_ctl[6] > big_cap) { c->stat.retries++; return KH_OK; }   // too many: the key-array form
         c->stat.big_slots += h_ctl[6];
         c->prof_begin(KC_SKM_UNION);
-        kh_launch_skm_big(job, cs, h_ctl[6], st);
+        if (two) kh_launch_skm2_big(job, cs, h_ctl[6], st);
+        else kh_launch_skm_big(job, cs, h_ctl[6], st);
         c->prof_end();
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_down, wsp, down_bytes, hipMemcpyDeviceToHost, st));

@@ -156,7 +156,7 @@ struct KhSkmJob {
     u32 nbins, abase, reps, nops;
     u32 table;                      // entries of the union's hash set: 4096 (1024 threads) or 2048 (512 threads); one-word keys
     // one-word keys: records of slots whose region is full (regroup) and the slots the union leaves to k_skm_big
-    uint4* spill_rec;               // [spill_cap]; nullptr: a full region is an error (two-word keys)
+    uint4* spill_rec;               // [spill_cap] records (one or two uint4 each); nullptr: a full region is an error
     u32* spill_slot;                // [spill_cap]
     u32* big_list;                  // [big_cap] slots with more records than their region holds
     u32 spill_cap, big_cap;         // counters: ctl[5] records spilled, ctl[6] slots listed
@@ -209,6 +209,7 @@ bool kh_skm2_supports_w(u32 w);
 u32 kh_skm2_max_cap2();
 u32 kh_skm2_table();
 u32 kh_skm2_union_per_cu();   // workgroups of the two-word union that fit a CU
+void kh_launch_skm2_big(const KhSkmJob& job, u32 cs, u32 nbig, hipStream_t st);
 size_t kh_skm2_scatter_lds_bytes(u32 nb1);
 size_t kh_skm2_regroup_lds_bytes(u32 S);
 size_t kh_skm2_union_lds_bytes(u32 nbins);

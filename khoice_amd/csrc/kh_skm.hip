@@ -557,7 +557,10 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
                         if (o.x == rx && o.y == ry && o.z == rz && ((o.w ^ rw) & ~(31u << 21)) == 0u) {
                             const u32 bit = 1u << (tg & 31u);
                             const u32 was = atomicOr(&rmask[old - 1u], bit);
-                            if (was & bit) atomicAdd(&dupc[tg], nj);   // a second copy inside one genome: nj repeats
+                            if (was & bit) {   // a second copy inside one genome: nj repeats
+                                atomicAdd(&dupc[tg], nj);
+                                rmask[tid] = 0u;   // (this record's own mask is unused: zero = "has counted repeats", should the slot be handed on below)
+                            }
                             pend = false;
                         } else {
                             hp = hp + 1u == T ? 0u : hp + 1u;
@@ -584,6 +587,13 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
         SKM_MARK("dedup_end");
         SKM_USTAMP(2);
         __syncthreads();   // the staged records and the set of contents are dead, the previous slot's masks are read: the table is made
+        if ((scratch[0] & 0xffffu) > G::MAXCH) {   // uniform, rare: the slot is handed to k_skm_big below; what the merge has counted is taken back
+            if (tid < nrec && rmask[tid] == 0u) {
+                const u32 w = stage[tid].w;
+                atomicSub(&dupc[(w >> 21) & 63u], w >> 27);
+            }
+            __syncthreads();
+        }
         // ---- the next slot's record sets out now, into the registers this slot's record has just left: it has the
         // expansion and the read-out to arrive
         rr = tid < nrec_next ? (jb.reg2 + (u64)(slot + stride) * cap2)[tid] : make_uint4(0, 0, 0, 0);
@@ -594,8 +604,13 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
         SKM_MARK("after_scan");
         st_full = N > st_full ? N : st_full;
         st_exp += N;
-        if (C > G::MAXCH) {   // uniform: a slot this full goes back to the host
-            if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+        if (C > G::MAXCH) {   // uniform: more chunks than are numbered here (long runs of one minimizer): k_skm_big takes the slot
+            if (tid == 0) {
+                if (jb.big_list) {
+                    const u32 at = atomicAdd(jb.ctl + 6, 1u);
+                    if (at < jb.big_cap) jb.big_list[at] = slot;
+                } else atomicOr(jb.ctl, KH_ERR_CAPACITY);
+            }
             C = 0;
             N = 0;
         }
@@ -875,7 +890,7 @@ __global__ __launch_bounds__(SKM_BIG_NT) void k_skm_big(const KhSkmJob jb, u32 c
         if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
         nside = SKM_BIG_IDX;
     }
-    const u32 nreg = cap2;   // (the region of an overfull slot is full)
+    const u32 nreg = jb.cur2[slot] < cap2 ? jb.cur2[slot] : cap2;   // (full for an overfull slot; a slot listed for its chunks may hold fewer)
     const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2;
     const u32 nall = nreg + nside;
     auto record = [&](u32 i) -> uint4 { return i < nreg ? reg[i] : jb.spill_rec[sidx[i - nreg]]; };

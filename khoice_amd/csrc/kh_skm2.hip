@@ -298,7 +298,9 @@ __global__ __launch_bounds__(SKM_RG_NT, 4) void k_skm2_regroup(const KhSkmJob jb
             nx[r][1] = i < cnt ? src[2 * i + 1] : make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
-        skm_flush<SKM_RG_NT, SKM2_RG_CAP, true, 8>(L, n, nfine, lcur, dst, jb.cap2, jb.ctl);
+        SkmSpill sp;
+        sp.rec = jb.spill_rec; sp.slot = jb.spill_slot; sp.n = jb.ctl + 5; sp.cap = jb.spill_cap; sp.first_slot = first_slot;
+        skm_flush<SKM_RG_NT, SKM2_RG_CAP, true, 8>(L, n, nfine, lcur, dst, jb.cap2, jb.ctl, sp);
     }
     for (u32 i = tid; i < nfine; i += SKM_RG_NT) jb.cur2[first_slot + i] = lcur[i];
 }
@@ -390,9 +392,9 @@ __global__ __launch_bounds__(SKM2_UNT, SKM2_UNT == 1024 ? 8 : 6) void k_skm2_uni
     typedef const u32 __attribute__((address_space(4))) * ConstU32;
     const ConstU32 counts = (ConstU32)(unsigned long long)jb.cur2;
     const u32 fit = cap2 < SKM2_MAXREC ? cap2 : SKM2_MAXREC;
-    auto count_of = [&](u32 sl) -> u32 {
+    auto count_of = [&](u32 sl) -> u32 {   // (an overfull slot is k_skm2_big's: empty here)
         const u32 n = sl < nslots ? counts[sl] : 0u;
-        return n < fit ? n : fit;
+        return n <= fit ? n : 0u;
     };
     if (tid < (u32)KH_TAG_MAX_OPS) {
         const u32 g = jb.ginfo[tid], g0 = g & 0xffu, gn = (g >> 8) & 0xffu;
@@ -432,7 +434,10 @@ __global__ __launch_bounds__(SKM2_UNT, SKM2_UNT == 1024 ? 8 : 6) void k_skm2_uni
         lane = tid & (KH_WAVE - 1u);
         const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2 * 2;
         const u32 nrec_after = count_of(slot + 2u * stride);
-        if (counts[slot] > fit && tid0 == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);   // (no side list with two-word keys: the host falls back)
+        if (counts[slot] > fit && tid0 == 0) {   // an overfull slot: listed for k_skm2_big
+            const u32 at = atomicAdd(jb.ctl + 6, 1u);
+            if (at < jb.big_cap) jb.big_list[at] = slot;
+        }
         // ---- stage this slot's records, one per thread
         u32 nj = 0;
         const u32 tg = rec2_tag(rb.w);
@@ -468,7 +473,10 @@ __global__ __launch_bounds__(SKM2_UNT, SKM2_UNT == 1024 ? 8 : 6) void k_skm2_uni
                             ((ob.w ^ b3) & ~(31u << 20)) == 0u) {   // the same bases and number of k-mers, a genome of the same half
                             const u32 bit = 1u << (tg & 31u);
                             const u32 was = atomicOr(&rmask[old - 1u], bit);
-                            if (was & bit) atomicAdd(&dupc[tg], nj);
+                            if (was & bit) {
+                                atomicAdd(&dupc[tg], nj);
+                                rmask[tid] = 0u;   // "has counted repeats" (taken back if the slot is handed to k_skm2_big)
+                            }
                             pend = false;
                         } else hp = hp + 1u == DD ? 0u : hp + 1u;
                     }
@@ -487,6 +495,13 @@ __global__ __launch_bounds__(SKM2_UNT, SKM2_UNT == 1024 ? 8 : 6) void k_skm2_uni
             }
         }
         __syncthreads();
+        if ((scratch[0] & 0xffffu) > SKM2_MAXCH) {   // uniform, rare: the slot goes to k_skm2_big below; what the merge has counted is taken back
+            if (tid < nrec && rmask[tid] == 0u) {
+                const u32 w = stage[2 * tid + 1].w;
+                atomicSub(&dupc[rec2_tag(w)], rec2_n(w));
+            }
+            __syncthreads();
+        }
         // ---- the next slot's record sets out; the table is made
         ra = make_uint4(0, 0, 0, 0); rb = make_uint4(0, 0, 0, 0);
         if (tid < nrec_next) { const uint4* r = jb.reg2 + ((u64)(slot + stride) * cap2 + tid) * 2; ra = r[0]; rb = r[1]; }
@@ -495,8 +510,13 @@ __global__ __launch_bounds__(SKM2_UNT, SKM2_UNT == 1024 ? 8 : 6) void k_skm2_uni
         u32 C = scratch[0] & 0xffffu, N = scratch[0] >> 16;
         st_full = N > st_full ? N : st_full;
         st_exp += N;
-        if (C > SKM2_MAXCH) {
-            if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+        if (C > SKM2_MAXCH) {   // uniform: more chunks than are numbered here: k_skm2_big takes the slot
+            if (tid == 0) {
+                if (jb.big_list) {
+                    const u32 at = atomicAdd(jb.ctl + 6, 1u);
+                    if (at < jb.big_cap) jb.big_list[at] = slot;
+                } else atomicOr(jb.ctl, KH_ERR_CAPACITY);
+            }
             C = 0;
             N = 0;
         }
@@ -667,6 +687,227 @@ __global__ __launch_bounds__(SKM2_UNT, SKM2_UNT == 1024 ? 8 : 6) void k_skm2_uni
 }
 
 // ------------------------------------------------------------------------------------------
+// Overfull slots with two-word keys (as k_skm_big in kh_skm.hip): one workgroup per listed slot takes the records in
+// its region and its records on the side list, every k-mer into a 2048-entry table in rounds of key subsets, read-out by
+// a scan of the table.  Nothing here is tuned: a handful of slots per run.
+// ------------------------------------------------------------------------------------------
+constexpr u32 SKM2_BIG_NT = 1024, SKM2_BIG_T = 2048, SKM2_BIG_T2 = 64, SKM2_BIG_IDX = 4096;
+constexpr u32 SKM2_BIG_BATCH = 128, SKM2_BIG_MAXCH = SKM2_BIG_BATCH << SKM2_OB;
+size_t kh_skm2_big_lds_bytes() {
+    return (size_t)SKM2_BIG_T * 24 + (size_t)SKM2_BIG_T2 * 24 + 1024 + 128 + 256 + (size_t)SKM2_HSTRIPE_WORDS * 4 +
+           (size_t)SKM2_BIG_MAXCH * 2 + (size_t)SKM2_BIG_IDX * 4;
+}
+__global__ __launch_bounds__(SKM2_BIG_NT) void k_skm2_big(const KhSkmJob jb, u32 cs) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    constexpr u32 NT = SKM2_BIG_NT, T = SKM2_BIG_T, T2 = SKM2_BIG_T2, HBITS = 11;
+    constexpr int E = (int)SKM2_UE;
+    constexpr u64 EMPTY = ~0ull;
+    u8* p = lds_raw;
+    unsigned long long* tklo = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T * 8;
+    unsigned long long* tkhi = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T * 8;
+    u32* tmlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T * 4;
+    u32* tmhi = reinterpret_cast<u32*>(p);                                 p += (size_t)T * 4;
+    unsigned long long* oklo = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T2 * 8;
+    unsigned long long* okhi = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T2 * 8;
+    u32* omlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
+    u32* omhi = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
+    uint4* gtab = reinterpret_cast<uint4*>(p);                             p += 1024;
+    u32* scratch = reinterpret_cast<u32*>(p);                              p += 128;
+    u32* dupc = reinterpret_cast<u32*>(p);                                 p += 256;
+    u32* hstripe = reinterpret_cast<u32*>(p);                              p += (size_t)SKM2_HSTRIPE_WORDS * 4;
+    u16* owner = reinterpret_cast<u16*>(p);                                p += (size_t)SKM2_BIG_MAXCH * 2;
+    u32* sidx = reinterpret_cast<u32*>(p);
+    const u32 tid = threadIdx.x, lane = lane_id();
+    const u32 nbins = jb.nbins, cap2 = jb.cap2;
+    const int k = jb.k;
+    const u32 slot = jb.big_list[blockIdx.x];
+    const u32 sshift = nbins <= 72u ? 2u : (nbins <= 144u ? 1u : 0u), smask = (1u << sshift) - 1u;
+    const u32 kb = 2 * (u32)k;
+    u32 km[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) km[i] = kb >= 32u * (i + 1) ? 0xffffffffu : (kb > 32u * i ? (1u << (kb - 32u * i)) - 1u : 0u);
+    const u64 kmhi = ((u64)km[3] << 32) | km[2];
+    const u32 fs = 128u - kb, tsh = kb - 2u - 64u;
+    if (tid < (u32)KH_TAG_MAX_OPS) {
+        const u32 g = jb.ginfo[tid], g0 = g & 0xffu, gn = (g >> 8) & 0xffu;
+        const u64 gm = gn ? (gn >= 64u ? ~0ull : ((1ull << gn) - 1ull)) << g0 : 0ull;
+        gtab[tid] = make_uint4((u32)gm, (u32)(gm >> 32), (g >> 16) << sshift, 0u);
+        dupc[tid] = 0;
+    }
+    if (tid < SKM2_HSTRIPE_WORDS) hstripe[tid] = 0;
+    if (tid < 8) scratch[tid] = 0;
+    __syncthreads();
+    u32 nspill_all = jb.ctl[5];
+    nspill_all = nspill_all < jb.spill_cap ? nspill_all : jb.spill_cap;
+    for (u32 i = tid; i < nspill_all; i += NT) {
+        if (jb.spill_slot[i] == slot) {
+            const u32 at = atomicAdd(&scratch[3], 1u);
+            if (at < SKM2_BIG_IDX) sidx[at] = i;
+        }
+    }
+    __syncthreads();
+    u32 nside = scratch[3];
+    if (nside > SKM2_BIG_IDX) {
+        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+        nside = SKM2_BIG_IDX;
+    }
+    const u32 nreg = jb.cur2[slot] < cap2 ? jb.cur2[slot] : cap2;
+    const uint4* __restrict__ reg = jb.reg2 + (u64)slot * cap2 * 2;
+    const u32 nall = nreg + nside;
+    auto rec_a = [&](u32 i) -> uint4 { return i < nreg ? reg[2 * i] : jb.spill_rec[2 * (u64)sidx[i - nreg]]; };
+    auto rec_b = [&](u32 i) -> uint4 { return i < nreg ? reg[2 * i + 1] : jb.spill_rec[2 * (u64)sidx[i - nreg] + 1]; };
+    {
+        u32 mine = 0;
+        for (u32 i = tid; i < nall; i += NT) mine += rec2_n(rec_b(i).w);
+        const u32 tot = wave_scan_add(mine);
+        if (lane == KH_WAVE - 1 && tot) atomicAdd(&scratch[2], tot);
+    }
+    __syncthreads();
+    const u32 N = scratch[2];
+    const u32 R = (N + 1535u) / 1536u;
+    if (tid == 0 && N > T) atomicMax(jb.ctl + 1, N);
+    auto eval_mask = [&](u32 mlo, u32 mhi) -> bool {
+        const u32 lsel = lane & smask;
+        u32 ng = 0;
+        do {
+            const u32 first = mlo ? (u32)__builtin_ctz(mlo) : 32u + (u32)__builtin_ctz(mhi);
+            const uint4 g = gtab[first];
+            u32 c = (u32)__popc(mlo & g.x) + (u32)__popc(mhi & g.y);
+            c = c < cs ? c : cs;
+            atomicAdd(&hstripe[g.z + (c << sshift) + lsel], 1u);
+            const u32 keep_hi = mlo ? ~0u : mhi - 1u;
+            mlo &= ~g.x & (mlo - 1u);
+            mhi &= ~g.y & keep_hi;
+            ++ng;
+        } while (mlo | mhi);
+        if (ng == 1u) return true;
+        atomicAdd(&hstripe[((jb.abase + (ng < cs ? ng : cs)) << sshift) + lsel], 1u);
+        return false;
+    };
+    for (u32 q = 0; q < R; ++q) {
+        for (u32 i = tid; i < T; i += NT) reinterpret_cast<uint4*>(tklo)[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        for (u32 i = tid; i < T / 2; i += NT) reinterpret_cast<uint4*>(tmlo)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < T2) { oklo[tid] = EMPTY; okhi[tid] = EMPTY; omlo[tid] = 0u; omhi[tid] = 0u; }
+        __syncthreads();
+        for (u32 b0 = 0; b0 < nall; b0 += SKM2_BIG_BATCH) {
+            const u32 mine_i = b0 + tid;
+            const u32 nj = tid < SKM2_BIG_BATCH && mine_i < nall ? rec2_n(rec_b(mine_i).w) : 0u;
+            const u32 nch = (nj + (u32)E - 1u) / (u32)E;
+            {
+                const u32 incl = wave_scan_add(nch);
+                u32 wbase = 0;
+                if (lane == KH_WAVE - 1 && incl) wbase = atomicAdd(&scratch[0], incl);
+                wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
+                const u32 cstart = wbase + incl - nch;
+                if (cstart + nch <= SKM2_BIG_MAXCH)
+                    for (u32 cc = 0; cc < nch; ++cc) owner[cstart + cc] = (u16)((tid << SKM2_OB) | cc);
+            }
+            __syncthreads();
+            u32 C = scratch[0];
+            if (C > SKM2_BIG_MAXCH) {
+                if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                C = 0;
+            }
+            for (u32 c = tid; c < C; c += NT) {
+                const u32 o = owner[c], ri = b0 + (o >> SKM2_OB), first = (o & ((1u << SKM2_OB) - 1u)) * (u32)E;
+                const uint4 a = rec_a(ri), b = rec_b(ri);
+                const u32 tg = rec2_tag(b.w), bit = 1u << (tg & 31u), half = tg >> 5;
+                const u32 left = rec2_n(b.w) - first;
+                const u32 cnt = left < (u32)E ? left : (u32)E;
+                const u32 sh = 2 * first, wq = sh >> 5, r5 = sh & 31u;
+                const u32 R0 = a.x, R1 = a.y, R2 = a.z, R3 = a.w, R4 = b.x, R5 = b.y, R6 = b.z, R7 = b.w & 0x3ffu;
+                const bool q1 = wq & 1u, q2 = wq & 2u;
+                auto sel = [&](u32 v0, u32 v1, u32 v2, u32 v3) -> u32 {
+                    const u32 lo2 = q1 ? v1 : v0, hi2 = q1 ? v3 : v2;
+                    return q2 ? hi2 : lo2;
+                };
+                const u32 s0 = sel(R0, R1, R2, R3), s1 = sel(R1, R2, R3, R4), s2 = sel(R2, R3, R4, R5),
+                          s3 = sel(R3, R4, R5, R6), s4 = sel(R4, R5, R6, R7);
+                u32 xw[4];
+                xw[0] = __builtin_amdgcn_alignbit(s1, s0, r5);
+                xw[1] = __builtin_amdgcn_alignbit(s2, s1, r5);
+                xw[2] = __builtin_amdgcn_alignbit(s3, s2, r5);
+                xw[3] = __builtin_amdgcn_alignbit(s4, s3, r5);
+                const u32 nbw = kb >= 96u ? xw[3] : xw[2];
+                const u32 nb = (nbw >> (kb & 31u)) & 3u;
+                const u32 x0 = xw[0] & km[0], x1 = xw[1] & km[1], x2 = xw[2] & km[2], x3 = xw[3] & km[3];
+                const u32 y0 = revpairs32(x3), y1 = revpairs32(x2), y2 = revpairs32(x1), y3 = revpairs32(x0);
+                const u64 ylo = ((u64)y1 << 32) | y0, yhi = ((u64)y3 << 32) | y2;
+                u64 flo = (ylo >> fs) | ((yhi << 1) << (63 - fs)), fhi = yhi >> fs;
+                u64 rlo = ((u64)(x1 ^ km[1]) << 32) | (x0 ^ km[0]), rhi = ((u64)(x3 ^ km[3]) << 32) | (x2 ^ km[2]);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (e) {
+                        fhi = ((fhi << 2) | (flo >> 62)) & kmhi;
+                        flo = (flo << 2) | nb;
+                        rlo = (rlo >> 2) | (rhi << 62);
+                        rhi = (rhi >> 2) | ((u64)(3u - nb) << tsh);
+                    }
+                    if ((u32)e >= cnt) break;
+                    const bool fwd = fhi < rhi || (fhi == rhi && flo < rlo);
+                    const unsigned long long KL = fwd ? flo : rlo, KH = fwd ? fhi : rhi;
+                    const u32 H = key2_hash(KL, KH);
+                    if (R != 1 && (((H >> 4) & 0xffffu) * R) >> 16 != q) continue;
+                    u32 S = H >> (32 - HBITS), probes = 0, level = 0;
+                    while (true) {
+                        unsigned long long* kl = level == 1 ? oklo : tklo;
+                        unsigned long long* kh = level == 1 ? okhi : tkhi;
+                        const unsigned long long o2 = atomicCAS(&kl[S], EMPTY, KL);
+                        bool hit = o2 == EMPTY;
+                        // the owners of this step publish their high words BEFORE any lane of the wave waits for one
+                        // (one if / else would let the waiting lanes run first and spin on a masked-off owner for ever)
+                        if (hit) __hip_atomic_store(&kh[S], KH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __builtin_amdgcn_wave_barrier();
+                        if (!hit && o2 == KL) {
+                            unsigned long long h2;
+                            do h2 = __hip_atomic_load(&kh[S], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            while (h2 == EMPTY);
+                            hit = h2 == KH;
+                        }
+                        if (hit) {
+                            u32* mp = level == 1 ? (half ? omhi : omlo) : (half ? tmhi : tmlo);
+                            if (atomicOr(mp + S, bit) & bit) atomicAdd(&dupc[tg], 1u);
+                            break;
+                        }
+                        ++probes;
+                        if (level == 0 && probes >= 4u) {
+                            level = 1; probes = 0;
+                            S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> 26;
+                        } else if (level == 1 && probes >= 8u) {
+                            level = 2; probes = 0;
+                            S = ((H >> (32 - HBITS)) + 4u) & (T - 1u);
+                        } else if (level == 2 && probes >= T) {
+                            atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                            break;
+                        } else {
+                            S = (S + 1u) & (level == 1 ? T2 - 1u : T - 1u);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) scratch[0] = 0;
+            __syncthreads();
+        }
+        u32 ones = 0;
+        for (u32 i = tid; i < T; i += NT)
+            if (tklo[i] != EMPTY && eval_mask(tmlo[i], tmhi[i])) ++ones;
+        if (tid < T2 && oklo[tid] != EMPTY && eval_mask(omlo[tid], omhi[tid])) ++ones;
+        ones = wave_scan_add(ones);
+        if (lane == KH_WAVE - 1 && ones) atomicAdd(&hstripe[(jb.abase + 1u) << sshift], ones);
+        __syncthreads();
+    }
+    unsigned long long* __restrict__ rep = jb.hist + (u64)(blockIdx.x % jb.reps) * nbins;
+    for (u32 i = tid; i < nbins; i += NT) {
+        u32 v = 0;
+        for (u32 j = 0; j <= smask; ++j) v += hstripe[(i << sshift) + j];
+        if (v) atomicAdd(&rep[i], (unsigned long long)v);
+    }
+    if (tid < (u32)KH_TAG_MAX_OPS && dupc[tid]) atomicAdd(&jb.dup[tid], (unsigned long long)dupc[tid]);
+    if (tid == 0) atomicAdd(jb.ctl + 3, N);
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 template <class K> static void skm2_allow_lds(K kern, size_t bytes) {
@@ -698,4 +939,10 @@ void kh_launch_skm2_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st)
     const size_t lds = kh_skm2_union_lds_bytes(job.nbins);
     skm2_allow_lds(k_skm2_union, lds);
     hipLaunchKernelGGL(k_skm2_union, dim3(grid), dim3(SKM2_UNT), lds, st, job, cs);
+}
+void kh_launch_skm2_big(const KhSkmJob& job, u32 cs, u32 nbig, hipStream_t st) {
+    if (!nbig) return;
+    const size_t lds = kh_skm2_big_lds_bytes();
+    skm2_allow_lds(k_skm2_big, lds);
+    hipLaunchKernelGGL(k_skm2_big, dim3(nbig), dim3(SKM2_BIG_NT), lds, st, job, cs);
 }

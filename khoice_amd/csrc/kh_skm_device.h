@@ -100,10 +100,10 @@ template <u32 CAP, u32 RW = 4> constexpr size_t flush_lds_bytes(u32 nbk_alloc) {
 // atomic (LOCAL == false: the scatter, whose buckets are shared by all workgroups) or from a cursor in LDS
 // (LOCAL: the regroup, where a workgroup owns its buckets).  nbk <= 2 * NT.
 // Entry: a barrier has made stage / sid / bcnt visible.  Exit: bcnt zeroed, a barrier passed.
-// Records of a slot whose region is full (regroup, one-word keys): they go to a global side list with the number of
+// Records of a slot whose region is full (regroup): they go to a global side list with the number of
 // their slot; the slots they belong to are taken by a kernel of their own afterwards (k_skm_big).
 struct SkmSpill {
-    uint4* rec = nullptr;     // [cap]
+    uint4* rec = nullptr;     // [cap] records (of one or two uint4)
     u32* slot = nullptr;      // [cap]
     u32* n = nullptr;         // records spilled so far (may run past cap: the host then falls back)
     u32 cap = 0;
@@ -180,9 +180,13 @@ __device__ __forceinline__ void skm_flush(const FlushLds& L, const u32 n, const 
             if (dest < region_cap) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) region[((u64)b * region_cap + dest) * Q + q] = L.stage[i * Q + q];
-            } else if (Q == 1 && sp.rec) {   // the slot's region is full
+            } else if (sp.rec) {   // the slot's region is full
                 const u32 at = atomicAdd(sp.n, 1u);
-                if (at < sp.cap) { sp.rec[at] = L.stage[i]; sp.slot[at] = sp.first_slot + b; }
+                if (at < sp.cap) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) sp.rec[(u64)at * Q + q] = L.stage[i * Q + q];
+                    sp.slot[at] = sp.first_slot + b;
+                }
             }
         }
     }
