@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <memory>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -189,7 +190,7 @@ void kh_ctx::prof_collect() {
 static const char* kClsNames[KC_COUNT] = {"extract_hist", "bucket_plan", "extract_scatter",
                                           "bucket_sort_rle", "range_bounds", "setop", "histogram",
                                           "remix", "copy_in", "union_tagged", "skm_scatter",
-                                          "skm_regroup", "skm_union"};
+                                          "skm_regroup", "skm_union", "skm_big", "skm_pack", "skm_phased"};
 
 // ------------------------------------------------------------------------------ ctx API
 extern "C" int kh_device_count(void) {
@@ -1539,6 +1540,8 @@ struct SkmRecords {
     const u32* cur2 = nullptr;  // out: [nslots] records per slot
     u32 nslots = 0, cap2 = 0;
     u64 records = 0;            // out: records written
+    u32 fan_hint = 0;           // in: genomes whose copies of a locus arrive together (tags of ONE group: the sub-batch size)
+    std::vector<u64>* inst = nullptr;   // out (if set): k-mer instances per sequence, in the caller's order
     ~SkmRecords() { buf_unref(reg2); buf_unref(ws); }
 };
 static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
@@ -1612,6 +1615,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     {
         u32 fan = 1;
         for (int g = 0; g < ngroups; ++g) fan = std::max<u32>(fan, (u32)gsize[g]);
+        if (rec_out && rec_out->fan_hint) fan = std::max(fan, rec_out->fan_hint);
         const double T = two ? (double)kh_skm2_table() : (double)table, cl = 0.5 * (double)(w + 1) * (double)fan;
         const double r = 0.5 * (-2.5 * std::sqrt(cl) + std::sqrt(6.25 * cl + 4.0 * T));
         mean = (u32)std::max(256.0, r * r);
@@ -1659,7 +1663,17 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     const double recs = (double)total_pos * per_kmer;
     if (const char* e = getenv("KHOICE_SKM_SLACK")) slack1 = slack2 = std::max(0.01, atof(e));   // below 1: tests of the overflow fall-back
     const u64 cap1_64 = ((u64)(recs / nb1 * slack1) + 2048 + 63) & ~63ull;
-    const u64 cap2_64 = ((u64)(recs / nslots * slack2) + 96 + 15) & ~15ull;
+    u64 cap2_64 = ((u64)(recs / nslots * slack2) + 96 + 15) & ~15ull;
+    if (cap2_64 > max_cap2 && !(rec_out && rec_out->force_slots)) {
+        // Large groups: the copies of a locus (one record per genome of the group) arrive in a slot together, so the
+        // five-sigma region is larger than the union takes.  The region is cut to what it takes and the slots with a
+        // locus too many go the side-list way (k_skm_big); only when there are more of those than the side list
+        // holds is the call given to the key arrays.  (Models of how many there will be — loci per slot Poisson, the
+        // group's genomes as one clump — were off by 10 x in both directions on synthetic sets: it is tried.)
+        u32 fan = 1;
+        for (int g = 0; g < ngroups; ++g) fan = std::max<u32>(fan, (u32)gsize[g]);
+        if ((double)fan + recs / (double)nslots <= (double)max_cap2 - 112.0) cap2_64 = max_cap2 & ~15u;
+    }
     if (cap2_64 > max_cap2 || cap1_64 > 0x7fffffffull) return KH_OK;
     const u32 cap1 = (u32)cap1_64, cap2 = (u32)cap2_64;
     const size_t rec_bytes = two ? 32 : 16;
@@ -1708,7 +1722,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
                  ws_bytes = off_tiles + sizeof(KhTile) * (size_t)std::max<u32>(1, ntiles);   // [ginfo .. tiles]: one upload
     Tmp d_seq, d_ws, d_reg1, d_reg2, d_spill;
     // one-word keys: what a slot's region cannot hold goes to a side list, the slot to a kernel of its own
-    const u32 spill_cap = 1u << 18, big_cap = 4096u;
+    const u32 spill_cap = 1u << 20, big_cap = 16384u;
     bool need_pack = false;
     for (int i = 0; i < nseq; ++i)
         if (!(on_device && (reinterpret_cast<uintptr_t>(seqs[perm[i]]) & 15) == 0)) need_pack = true;
@@ -1808,6 +1822,13 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         // (records on the side list are not part of what is handed out: an overfull slot is a failure here)
         if ((h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER)) || h_ctl[5]) { c->stat.retries++; return KH_OK; }
         c->stat.skm_records += h_ctl[2];
+        if (rec_out->inst) {
+            std::vector<u64> hi(nseq);
+            HIPCHK(hipMemcpyAsync(hi.data(), job.inst, 8 * (size_t)nseq, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            rec_out->inst->assign(nseq, 0);
+            for (int i = 0; i < nseq; ++i) (*rec_out->inst)[perm[i]] = hi[i];
+        }
         rec_out->records = h_ctl[2];
         rec_out->reg2 = d_reg2.b; d_reg2.b = nullptr;
         rec_out->ws = d_ws.b; d_ws.b = nullptr;
@@ -1851,7 +1872,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         // them out; one workgroup each now, and the read-back again — only these slots are done twice, not the call
         if (h_ctl[5] > spill_cap || h_ctl[6] > big_cap) { c->stat.retries++; return KH_OK; }   // too many: the key-array form
         c->stat.big_slots += h_ctl[6];
-        c->prof_begin(KC_SKM_UNION);
+        c->prof_begin(KC_SKM_BIG);
         if (two) kh_launch_skm2_big(job, cs, h_ctl[6], st);
         else kh_launch_skm_big(job, cs, h_ctl[6], st);
         c->prof_end();
@@ -2096,6 +2117,8 @@ static int exp1_fused(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uin
     return KH_OK;
 }
 
+static int exp1_big_group_skm(kh_ctx* c, int n, const uint8_t* const* seqs, const uint64_t* lens, int on_device, int k, u32 cs,
+                              uint64_t* whist, u32 hist_len, uint64_t* dist, bool* done);
 extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens,
                            int on_device, const int* group_of, int ngroups, int k, uint32_t cs,
                            uint64_t* within_hist, uint64_t* across_hist, uint32_t hist_len,
@@ -2170,6 +2193,21 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
             std::vector<int> members;
             for (int i = 0; i < nseq; ++i)
                 if (group_of[i] == g) members.push_back(i);
+            if (!group_set && whist) {   // histogram and distinct counts only: the super-k-mer form in phases
+                std::vector<const uint8_t*> ms(members.size());
+                std::vector<uint64_t> ml(members.size()), md(members.size(), 0);
+                for (size_t j = 0; j < members.size(); ++j) { ms[j] = seqs[members[j]]; ml[j] = lens[members[j]]; }
+                const Stats before = c->stat;
+                KHCHK(exp1_big_group_skm(c, (int)members.size(), ms.data(), ml.data(), on_device, k, cs, whist, hist_len, md.data(), done));
+                if (*done) {
+                    if (dist_out)
+                        for (size_t j = 0; j < members.size(); ++j) dist_out[members[j]] = md[j];
+                    return KH_OK;
+                }
+                const u64 tries = c->stat.retries;   // (work counted by an attempt that was given up is forgotten, the attempt is not)
+                c->stat = before;
+                c->stat.retries = tries;
+            }
             std::vector<kh_set*> subs;
             struct G { std::vector<kh_set*>& v; ~G() { for (auto* x : v) kh_set_free(x); } } guard{subs};
             for (size_t i0 = 0; i0 < members.size(); i0 += KH_TAG_MAX_OPS) {
@@ -2456,10 +2494,8 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
 // numbers the ranks have agreed on (the largest rank's k-mer positions, the largest group).
 static bool skm_exchange_k(int k) { return k >= KH_SKM_MIN_K && k <= KH_SKM_MAX_K; }
 
-extern "C" int kh_skm_exchange_plan(kh_ctx* c, int k, uint64_t positions_max, uint32_t fan_max, int nparts, uint32_t* nslots,
-                                    uint32_t* slots_per_part, uint64_t* part_cap) {
-    if (!c || !nslots || !slots_per_part || !part_cap || nparts < 1) return kh_fail(KH_E_ARG, "kh_skm_exchange_plan: bad argument");
-    if (!skm_exchange_k(k)) return kh_fail(KH_E_ARG, "the exchange form takes k = %d .. %d", KH_SKM_MIN_K, KH_SKM_MAX_K);
+// slots for `nparts` pieces of at most positions_max k-mer positions each; false: too many k-mers per piece
+static bool skm_exchange_geometry(int k, uint64_t positions_max, int nparts, u64* nslots, double* per_kmer_out) {
     const int m15w = k - 15 + 1;
     int m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;
     if (k < 20) m = std::max(11, k - 6);
@@ -2468,7 +2504,6 @@ extern "C" int kh_skm_exchange_plan(kh_ctx* c, int k, uint64_t positions_max, ui
     // has to hold the slot's distinct k-mers of ALL ranks — sized for unrelated groups: nparts x the per-rank mean
     // below three quarters of it
     const double per_kmer = 2.0 / (double)(w + 1) + 1.0 / 48.0;
-    (void)fan_max;
     // k-mer instances per slot and rank.  The owner's table (4096 entries) takes ~3000 instances per round: with
     // groups of related genomes about 0.55 of a rank's instances survive the merge of identical records, so
     // 2600 / (0.55 x nparts) per rank keeps the owner at one round (unrelated genomes: two).  A rank's slot must also
@@ -2478,7 +2513,19 @@ extern "C" int kh_skm_exchange_plan(kh_ctx* c, int k, uint64_t positions_max, ui
     if (const char* e = getenv("KHOICE_SKM_EXCHANGE_MEAN")) mean = std::max(16.0, atof(e));   // tests: rounds on the owner
     u64 ns = std::max<u64>((u64)nparts, (u64)((double)std::max<u64>(1, positions_max) / mean) + 1);
     ns = std::min<u64>(ns, (u64)KH_SKM2_MAX_COARSE * KH_SKM_MAX_FINE);
-    if ((double)positions_max / (double)ns * per_kmer * 1.7 + 128.0 > 1024.0)
+    if ((double)positions_max / (double)ns * per_kmer * 1.7 + 128.0 > 1024.0) return false;
+    *nslots = ns;
+    *per_kmer_out = per_kmer;
+    return true;
+}
+extern "C" int kh_skm_exchange_plan(kh_ctx* c, int k, uint64_t positions_max, uint32_t fan_max, int nparts, uint32_t* nslots,
+                                    uint32_t* slots_per_part, uint64_t* part_cap) {
+    if (!c || !nslots || !slots_per_part || !part_cap || nparts < 1) return kh_fail(KH_E_ARG, "kh_skm_exchange_plan: bad argument");
+    if (!skm_exchange_k(k)) return kh_fail(KH_E_ARG, "the exchange form takes k = %d .. %d", KH_SKM_MIN_K, KH_SKM_MAX_K);
+    (void)fan_max;
+    u64 ns = 0;
+    double per_kmer = 0;
+    if (!skm_exchange_geometry(k, positions_max, nparts, &ns, &per_kmer))
         return kh_fail(KH_E_CAPACITY, "too many k-mers per rank for the exchange form (%llu positions)", (unsigned long long)positions_max);
     *nslots = (u32)ns;
     *slots_per_part = (u32)((ns + nparts - 1) / nparts);
@@ -2486,9 +2533,24 @@ extern "C" int kh_skm_exchange_plan(kh_ctx* c, int k, uint64_t positions_max, ui
     return KH_OK;
 }
 
+// fan_hint / inst_out / dup_out: the one-GPU use (a group of more than 64 genomes in sub-batches, exp1_big_group_skm):
+// the tags are genomes of ONE group, their instance counts and the repeats under one tag are wanted.  soft: what does
+// not fit is *done = false instead of an error.
+static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
+                         const int* tag_of, int k, uint32_t nslots, int nparts, uint64_t part_cap, void* rec_out,
+                         uint32_t* mask_out, uint32_t* count_out, uint32_t* off_out, uint64_t* part_n, u32 fan_hint,
+                         std::vector<u64>* inst_out, u64* dup_out /* [32] host */, bool* soft_done);
 extern "C" int kh_skm_pack(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                            const int* tag_of, int k, uint32_t nslots, int nparts, uint64_t part_cap, void* rec_out,
                            uint32_t* mask_out, uint32_t* count_out, uint32_t* off_out, uint64_t* part_n) {
+    return skm_pack_impl(c, nseq, seqs, lens, on_device, tag_of, k, nslots, nparts, part_cap, rec_out, mask_out, count_out, off_out,
+                         part_n, 0, nullptr, nullptr, nullptr);
+}
+static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
+                         const int* tag_of, int k, uint32_t nslots, int nparts, uint64_t part_cap, void* rec_out,
+                         uint32_t* mask_out, uint32_t* count_out, uint32_t* off_out, uint64_t* part_n, u32 fan_hint,
+                         std::vector<u64>* inst_out, u64* dup_out, bool* soft_done) {
+    if (soft_done) *soft_done = false;
     if (!c || !seqs || !lens || !tag_of || nseq <= 0 || nparts < 1 || !rec_out || !mask_out || !count_out || !off_out || !part_n)
         return kh_fail(KH_E_ARG, "kh_skm_pack: bad argument");
     if (!skm_exchange_k(k)) return kh_fail(KH_E_ARG, "the exchange form takes k = %d .. %d", KH_SKM_MIN_K, KH_SKM_MAX_K);
@@ -2501,6 +2563,8 @@ extern "C" int kh_skm_pack(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
     hipStream_t st = c->st;
     SkmRecords rec;
     rec.force_slots = nslots;
+    rec.fan_hint = fan_hint;
+    rec.inst = inst_out;
     bool done = false;
     {   // every tag needs a sequence for the geometry code (groups without genomes are refused there): tags are dense here
         std::vector<int> seen(ntags, 0);
@@ -2509,11 +2573,15 @@ extern "C" int kh_skm_pack(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
             if (!seen[t]) return kh_fail(KH_E_ARG, "kh_skm_pack: tag %d has no sequence", t);
     }
     KHCHK(exp1_skm(c, nseq, seqs, lens, on_device, tag_of, ntags, k, 1, nullptr, nullptr, 2, nullptr, &done, /*by_group=*/true, &rec));
-    if (!done) return kh_fail(KH_E_CAPACITY, "kh_skm_pack: the records did not fit their regions (low-complexity input?)");
+    if (!done) {
+        if (soft_done) return KH_OK;
+        return kh_fail(KH_E_CAPACITY, "kh_skm_pack: the records did not fit their regions (low-complexity input?)");
+    }
     const u32 spp = (rec.nslots + (u32)nparts - 1) / (u32)nparts;
     Tmp d_ctl;
-    TMP_ALLOC(d_ctl, c, 64 + 4 * (size_t)nparts);
-    HIPCHK(hipMemsetAsync(d_ctl.b->p, 0, 64 + 4 * (size_t)nparts, st));
+    const size_t off_dup = (64 + 4 * (size_t)nparts + 7) & ~(size_t)7, ctl_bytes = off_dup + 8 * 32;
+    TMP_ALLOC(d_ctl, c, ctl_bytes);
+    HIPCHK(hipMemsetAsync(d_ctl.b->p, 0, ctl_bytes, st));
     HIPCHK(hipMemsetAsync(count_out, 0, 4 * (size_t)spp * nparts, st));   // (slots past the last one: nothing)
     HIPCHK(hipMemsetAsync(off_out, 0, 4 * (size_t)spp * nparts, st));
     KhSkmPackJob job;
@@ -2525,33 +2593,49 @@ extern "C" int kh_skm_pack(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
     job.slot_count = count_out;
     job.slot_off = off_out;
     job.ctl = d_ctl.as<u32>();
+    job.dup = dup_out ? reinterpret_cast<unsigned long long*>(d_ctl.as<u8>() + off_dup) : nullptr;
     job.part_cap = part_cap;
     job.cap2 = rec.cap2;
     job.nslots = rec.nslots;
     job.spp = spp;
-    c->prof_begin(KC_SKM_UNION);
+    c->prof_begin(KC_SKM_PACK);
     kh_launch_skm_pack(job, st);
     c->prof_end();
     HIPCHK(hipGetLastError());
-    std::vector<u32> h(16 + nparts);
-    HIPCHK(hipMemcpyAsync(h.data(), d_ctl.b->p, 64 + 4 * (size_t)nparts, hipMemcpyDeviceToHost, st));
+    std::vector<u32> h(ctl_bytes / 4);
+    HIPCHK(hipMemcpyAsync(h.data(), d_ctl.b->p, ctl_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (h[0] & KH_ERR_ORDER) return kh_fail(KH_E_INTERNAL, "kh_skm_pack: a record carried a tag above 31");
-    if (h[0] & KH_ERR_CAPACITY) return kh_fail(KH_E_CAPACITY, "kh_skm_pack: a slot or a part overflowed");
+    if (h[0] & KH_ERR_CAPACITY) {
+        if (soft_done) return KH_OK;
+        return kh_fail(KH_E_CAPACITY, "kh_skm_pack: a slot or a part overflowed");
+    }
     for (int p = 0; p < nparts; ++p) part_n[p] = h[16 + p];
+    if (dup_out) memcpy(dup_out, reinterpret_cast<const u8*>(h.data()) + off_dup, 8 * 32);
+    if (soft_done) *soft_done = true;
     return KH_OK;
 }
 
+static int skm_phased_impl(kh_ctx* c, int k, int npieces, const void* const* recs, const uint32_t* const* masks,
+                           const uint32_t* const* counts, const uint32_t* const* offs, uint32_t nslots, uint32_t cs,
+                           uint64_t* hist, uint32_t hist_len, u64* dup_out /* [npieces][32] host or null */, bool* soft_done);
 extern "C" int kh_skm_phased_histogram(kh_ctx* c, int k, int npieces, const void* const* recs, const uint32_t* const* masks,
                                        const uint32_t* const* counts, const uint32_t* const* offs, uint32_t nslots, uint32_t cs,
                                        uint64_t* hist, uint32_t hist_len) {
+    return skm_phased_impl(c, k, npieces, recs, masks, counts, offs, nslots, cs, hist, hist_len, nullptr, nullptr);
+}
+static int skm_phased_impl(kh_ctx* c, int k, int npieces, const void* const* recs, const uint32_t* const* masks,
+                           const uint32_t* const* counts, const uint32_t* const* offs, uint32_t nslots, uint32_t cs,
+                           uint64_t* hist, uint32_t hist_len, u64* dup_out, bool* soft_done) {
+    if (soft_done) *soft_done = false;
     if (!c || npieces < 1 || !recs || !masks || !counts || !offs || !hist || hist_len < 2 || cs < 1)
         return kh_fail(KH_E_ARG, "kh_skm_phased_histogram: bad argument");
+    if (dup_out && npieces > (int)KH_SKM_PHASED_MAX_DUP_PIECES) return kh_fail(KH_E_ARG, "kh_skm_phased_histogram: too many pieces");
     if (!skm_exchange_k(k)) return kh_fail(KH_E_ARG, "the exchange form takes k = %d .. %d", KH_SKM_MIN_K, KH_SKM_MAX_K);
     HIPCHK(hipSetDevice(c->dev));
     hipStream_t st = c->st;
     const size_t off_pieces = 64, off_hist = (off_pieces + sizeof(KhSkmPiece) * (size_t)npieces + 63) & ~(size_t)63;
-    const size_t ws_bytes = off_hist + 8 * (size_t)hist_len;
+    const size_t off_pdup = off_hist + 8 * (size_t)hist_len, ws_bytes = off_pdup + (dup_out ? 8 * 32 * (size_t)npieces : 0);
     Tmp d_ws;
     TMP_ALLOC(d_ws, c, ws_bytes);
     std::vector<u8> up(off_hist, 0);
@@ -2568,21 +2652,114 @@ extern "C" int kh_skm_phased_histogram(kh_ctx* c, int k, int npieces, const void
     job.pieces = reinterpret_cast<const KhSkmPiece*>(d_ws.as<u8>() + off_pieces);
     job.hist = reinterpret_cast<unsigned long long*>(d_ws.as<u8>() + off_hist);
     job.ctl = d_ws.as<u32>();
+    job.dup = dup_out ? reinterpret_cast<unsigned long long*>(d_ws.as<u8>() + off_pdup) : nullptr;
     job.npieces = (u32)npieces;
     job.nslots = nslots;
     job.hist_len = hist_len;
     job.cs = cs;
     job.k = k;
-    c->prof_begin(KC_SKM_UNION);
+    c->prof_begin(KC_SKM_PHASED);
     kh_launch_skm_phased(job, std::min<u32>(std::max<u32>(1, nslots), 2u * (u32)std::max(1, c->cus)), st);
     c->prof_end();
     HIPCHK(hipGetLastError());
     u32 h_ctl[4];
     HIPCHK(hipMemcpyAsync(h_ctl, d_ws.b->p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hist, d_ws.as<u8>() + off_hist, 8 * (size_t)hist_len, hipMemcpyDeviceToHost, st));
+    if (dup_out) HIPCHK(hipMemcpyAsync(dup_out, d_ws.as<u8>() + off_pdup, 8 * 32 * (size_t)npieces, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (h_ctl[0] & KH_ERR_CAPACITY) return kh_fail(KH_E_CAPACITY, "kh_skm_phased_histogram: a slot held more k-mers than its table");
+    if (h_ctl[0] & KH_ERR_CAPACITY) {
+        if (soft_done) return KH_OK;
+        return kh_fail(KH_E_CAPACITY, "kh_skm_phased_histogram: a slot held more k-mers than its table");
+    }
     c->stat.setops++;
+    if (soft_done) *soft_done = true;
+    return KH_OK;
+}
+
+// One group of more than 64 genomes in the super-k-mer form (one-word keys): sub-batches of up to 32 genomes, each
+// turned into records tagged with the genome's number in the sub-batch, identical records merged (k_skm_pack, one
+// part); the sub-batches are the PHASES of one phased union (k_skm_phased): the counter of an entry ends as "in how
+// many genomes of the group", which is the group's step_4 histogram.  Distinct k-mers of a genome: its instances minus
+// the repeats under its tag (whole records at the merge, single k-mers at the insertion).  *done == false: the
+// caller takes the key-array sub-batches.
+static int exp1_big_group_skm(kh_ctx* c, int n, const uint8_t* const* seqs, const uint64_t* lens, int on_device, int k, u32 cs,
+                              uint64_t* whist, u32 hist_len, uint64_t* dist /* [n] or null */, bool* done) {
+    *done = false;
+    if (!skm_exchange_k(k) || getenv("KHOICE_NO_SKM") || getenv("KHOICE_NO_SKM_PHASED") || !whist) return KH_OK;
+    constexpr int SUB = 32;
+    const int P = (n + SUB - 1) / SUB;
+    if (P > (int)KH_SKM_PHASED_MAX_DUP_PIECES) return KH_OK;
+    std::vector<int> first(P + 1, 0);
+    for (int p = 0; p < P; ++p) first[p + 1] = first[p] + (n - first[p] + (P - p) - 1) / (P - p);   // balanced sizes
+    u64 pos_max = 0;
+    std::vector<u64> pos(P, 0);
+    for (int p = 0; p < P; ++p) {
+        for (int i = first[p]; i < first[p + 1]; ++i) pos[p] += lens[i] >= (u64)k ? lens[i] - k + 1 : 0;
+        pos_max = std::max(pos_max, pos[p]);
+    }
+    if (!pos_max) return KH_OK;
+    u64 ns = 0;
+    double per_kmer = 0;
+    const bool dbg = getenv("KHOICE_SKM_DEBUG") != nullptr;
+    if (!skm_exchange_geometry(k, pos_max, P, &ns, &per_kmer)) {
+        if (dbg) fprintf(stderr, "[skm phased] %d genomes in %d phases: no geometry for %llu positions per phase\n", n, P, (unsigned long long)pos_max);
+        return KH_OK;
+    }
+    const u32 nslots = (u32)ns;
+    if (dbg) fprintf(stderr, "[skm phased] %d genomes in %d phases, %u slots, %.0f positions per slot and phase\n", n, P, nslots, (double)pos_max / nslots);
+    HIPCHK(hipSetDevice(c->dev));
+    std::vector<std::unique_ptr<Tmp>> bufs;
+    std::vector<const void*> recs(P);
+    std::vector<const uint32_t*> masks(P), counts(P), offs(P);
+    std::vector<u64> inst_all(n, 0), dup_all(n, 0);
+    for (int p = 0; p < P; ++p) {
+        const int m = first[p + 1] - first[p];
+        const u64 cap = ((u64)((double)pos[p] * per_kmer * 1.3) + 8192 + 63) & ~63ull;
+        const size_t off_mask = 16 * (size_t)cap, off_count = off_mask + 4 * (size_t)cap, off_off = off_count + 4 * (size_t)((nslots + 3) & ~3u),
+                     bytes = off_off + 4 * (size_t)((nslots + 3) & ~3u);
+        bufs.emplace_back(new Tmp);
+        TMP_ALLOC(*bufs.back(), c, bytes);
+        u8* base = bufs.back()->as<u8>();
+        std::vector<int> tag(m);
+        for (int j = 0; j < m; ++j) tag[j] = j;
+        std::vector<u64> inst;
+        u64 dup[32], part_n = 0;
+        bool ok = false;
+        KHCHK(skm_pack_impl(c, m, seqs + first[p], lens + first[p], on_device, tag.data(), k, nslots, 1, cap, base,
+                            reinterpret_cast<u32*>(base + off_mask), reinterpret_cast<u32*>(base + off_count),
+                            reinterpret_cast<u32*>(base + off_off), &part_n, (u32)m, &inst, dup, &ok));
+        if (!ok) {
+            if (dbg) fprintf(stderr, "[skm phased] phase %d: the records did not fit\n", p);
+            return KH_OK;
+        }
+        if (dbg) fprintf(stderr, "[skm phased] phase %d: %llu records travel (cap %llu)\n", p, (unsigned long long)part_n, (unsigned long long)cap);
+        recs[p] = base;
+        masks[p] = reinterpret_cast<const u32*>(base + off_mask);
+        counts[p] = reinterpret_cast<const u32*>(base + off_count);
+        offs[p] = reinterpret_cast<const u32*>(base + off_off);
+        for (int j = 0; j < m; ++j) { inst_all[first[p] + j] = inst[j]; dup_all[first[p] + j] = dup[j]; }
+    }
+    std::vector<u64> pdup((size_t)P * 32, 0), hist(hist_len, 0);
+    bool ok = false;
+    KHCHK(skm_phased_impl(c, k, P, recs.data(), masks.data(), counts.data(), offs.data(), nslots, cs, hist.data(), hist_len, pdup.data(), &ok));
+    if (!ok) {
+        if (dbg) fprintf(stderr, "[skm phased] the phased union overflowed\n");
+        return KH_OK;
+    }
+    memcpy(whist, hist.data(), 8 * (size_t)hist_len);
+    u64 bases = 0, isum = 0, dsum = 0;
+    for (int p = 0; p < P; ++p)
+        for (int i = first[p]; i < first[p + 1]; ++i) {
+            const u64 d = inst_all[i] - dup_all[i] - pdup[(size_t)p * 32 + (i - first[p])];
+            if (dist) dist[i] = d;
+            bases += lens[i]; isum += inst_all[i]; dsum += d;
+        }
+    c->stat.bases += bases;
+    c->stat.builds += n;
+    c->stat.kmers += isum;
+    c->stat.distinct += dsum;
+    c->stat.setop_in += dsum;
+    *done = true;
     return KH_OK;
 }
 

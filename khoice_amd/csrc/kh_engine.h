@@ -31,7 +31,7 @@ void buf_unref(DevBuf* b);
 enum KernelClass {
     KC_EXTRACT_HIST = 0, KC_BUCKET_PLAN, KC_EXTRACT_SCATTER, KC_BUCKET_SORT, KC_RANGE_BOUNDS,
     KC_SETOP, KC_HISTOGRAM, KC_REMIX, KC_COPY_IN, KC_UNION_TAGGED, KC_SKM_SCATTER, KC_SKM_REGROUP, KC_SKM_UNION,
-    KC_COUNT
+    KC_SKM_BIG, KC_SKM_PACK, KC_SKM_PHASED, KC_COUNT
 };
 struct ProfEvt { int cls; hipEvent_t a, b; };
 struct Stats {

@@ -181,6 +181,7 @@ struct KhSkmPackJob {
     u32* slot_count;                // [nslots] records that travel
     u32* slot_off;                  // [nslots] where they start in their part's array
     u32* ctl;                       // [0] error bits
+    unsigned long long* dup;        // [32] or null: per tag, k-mer instances of records that repeat one of the SAME tag
     u64 part_cap;
     u32 cap2, nslots, spp;          // spp: slots per part (slot s belongs to part s / spp)
 };
@@ -194,9 +195,11 @@ struct KhSkmPhasedJob {
     const KhSkmPiece* pieces;       // device array [npieces]
     unsigned long long* hist;       // [hist_len], zeroed
     u32* ctl;                       // [0] error bits
+    unsigned long long* dup;        // [npieces][32] or null: per (piece, tag), instances that repeat a k-mer of the same tag
     u32 npieces, nslots, hist_len, cs;
     int k;
 };
+constexpr u32 KH_SKM_PHASED_MAX_DUP_PIECES = 32;   // pieces whose repeats can be counted (LDS counters)
 size_t kh_skm_pack_lds_bytes();
 size_t kh_skm_phased_lds_bytes();
 void kh_launch_skm_pack(const KhSkmPackJob& job, hipStream_t st);

@@ -1093,7 +1093,9 @@ __global__ __launch_bounds__(SKM_PK_NT) void k_skm_pack(const KhSkmPackJob jb) {
                 else {
                     const uint4 o = stage[old - 1u];
                     if (o.x == rr.x && o.y == rr.y && o.z == rr.z && ((o.w ^ rr.w) & ~(31u << 21)) == 0u) {
-                        atomicOr(&rmask[old - 1u], 1u << (tg & 31u));
+                        const u32 bit = 1u << (tg & 31u);
+                        const u32 was = atomicOr(&rmask[old - 1u], bit);
+                        if ((was & bit) && jb.dup) atomicAdd(&jb.dup[tg & 31u], (unsigned long long)nj);   // a second copy under one tag
                         pend = false;
                     } else hp = (hp + 1u) & (T - 1u);
                 }
@@ -1128,7 +1130,8 @@ __global__ __launch_bounds__(SKM_PK_NT) void k_skm_pack(const KhSkmPackJob jb) {
 constexpr u32 SKM_PH_NT = 1024, SKM_PH_T = 4096, SKM_PH_T2 = 128, SKM_PH_MAXCH = 3072, SKM_PH_HBINS = 512;
 constexpr u32 SKM_PH_ROUND = 3072;   // k-mer instances a round of the phased union takes (the table has 4096 entries)
 size_t kh_skm_phased_lds_bytes() {
-    return (size_t)SKM_PH_T * 16 + (size_t)SKM_PH_T2 * 16 + 128 + (size_t)SKM_PH_HBINS * 4 + (size_t)SKM_PH_MAXCH * 2;
+    return (size_t)SKM_PH_T * 16 + (size_t)SKM_PH_T2 * 16 + 128 + (size_t)SKM_PH_HBINS * 4 + (size_t)SKM_PH_MAXCH * 2 +
+           (size_t)KH_SKM_PHASED_MAX_DUP_PIECES * 32 * 4;
 }
 
 __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJob jb) {
@@ -1145,7 +1148,8 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
     u32* ocnt = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
     u32* scratch = reinterpret_cast<u32*>(p);                              p += 128;   // [0] chunks of the phase, [1] entries made, [2] k-mers of the slot
     u32* lhist = reinterpret_cast<u32*>(p);                                p += (size_t)SKM_PH_HBINS * 4;
-    u16* owner = reinterpret_cast<u16*>(p);
+    u16* owner = reinterpret_cast<u16*>(p);                                p += (size_t)SKM_PH_MAXCH * 2;
+    u32* dupc = reinterpret_cast<u32*>(p);                                 // [pieces][32] repeats under one tag (jb.dup)
     const u32 tid0 = threadIdx.x;
     u32 tid = tid0, lane = lane_id();
     const int k = jb.k;
@@ -1153,7 +1157,9 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
     const bool tsh_high = tsh >= 32u;
     const u32 tsh_sub = tsh_high ? tsh - 32u : tsh;
     const u32 hbins = jb.hist_len < SKM_PH_HBINS ? jb.hist_len : SKM_PH_HBINS;   // counts below this: LDS; above: global atomics
+    const bool want_dup = jb.dup != nullptr;
     typedef const u32 __attribute__((address_space(4))) * ConstU32;
+    if (want_dup) dupc[tid] = 0;   // (KH_SKM_PHASED_MAX_DUP_PIECES x 32 = the workgroup's 1024 threads)
     if (tid < SKM_PH_HBINS) lhist[tid] = 0;
     if (tid < 4) scratch[tid] = 0;
     __syncthreads();
@@ -1260,7 +1266,10 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
                             unsigned long long* kp = level == 1 ? okey : tkey;
                             const unsigned long long o2 = atomicCAS(&kp[S], emptyv, K);
                             if (o2 == emptyv || o2 == K) {
-                                atomicOr((level == 1 ? omlo : tmlo) + S, bits);
+                                if (want_dup) {   // uniform: bits set already = a second instance under that tag
+                                    u32 d = atomicOr((level == 1 ? omlo : tmlo) + S, bits) & bits;
+                                    while (d) { atomicAdd(&dupc[ph * 32u + (u32)__builtin_ctz(d)], 1u); d &= d - 1u; }
+                                } else atomicOr((level == 1 ? omlo : tmlo) + S, bits);
                                 if (o2 == emptyv) ++fresh_n;
                                 break;
                             }
@@ -1329,6 +1338,7 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
     }
     __syncthreads();
     if (tid0 < hbins && lhist[tid0]) atomicAdd(&jb.hist[tid0], (unsigned long long)lhist[tid0]);
+    if (want_dup && tid0 < jb.npieces * 32u && dupc[tid0]) atomicAdd(&jb.dup[tid0], (unsigned long long)dupc[tid0]);
 }
 
 // ------------------------------------------------------------------------------------------
