@@ -2539,7 +2539,7 @@ extern "C" int kh_skm_exchange_plan(kh_ctx* c, int k, uint64_t positions_max, ui
 static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                          const int* tag_of, int k, uint32_t nslots, int nparts, uint64_t part_cap, void* rec_out,
                          uint32_t* mask_out, uint32_t* count_out, uint32_t* off_out, uint64_t* part_n, u32 fan_hint,
-                         std::vector<u64>* inst_out, u64* dup_out /* [32] host */, bool* soft_done);
+                         std::vector<u64>* inst_out, u64* dup_out /* [32] host */, bool* soft_done, u32 nsub = 1);
 extern "C" int kh_skm_pack(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                            const int* tag_of, int k, uint32_t nslots, int nparts, uint64_t part_cap, void* rec_out,
                            uint32_t* mask_out, uint32_t* count_out, uint32_t* off_out, uint64_t* part_n) {
@@ -2549,7 +2549,7 @@ extern "C" int kh_skm_pack(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
 static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                          const int* tag_of, int k, uint32_t nslots, int nparts, uint64_t part_cap, void* rec_out,
                          uint32_t* mask_out, uint32_t* count_out, uint32_t* off_out, uint64_t* part_n, u32 fan_hint,
-                         std::vector<u64>* inst_out, u64* dup_out, bool* soft_done) {
+                         std::vector<u64>* inst_out, u64* dup_out, bool* soft_done, u32 nsub) {
     if (soft_done) *soft_done = false;
     if (!c || !seqs || !lens || !tag_of || nseq <= 0 || nparts < 1 || !rec_out || !mask_out || !count_out || !off_out || !part_n)
         return kh_fail(KH_E_ARG, "kh_skm_pack: bad argument");
@@ -2579,7 +2579,8 @@ static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const 
     }
     const u32 spp = (rec.nslots + (u32)nparts - 1) / (u32)nparts;
     Tmp d_ctl;
-    const size_t off_dup = (64 + 4 * (size_t)nparts + 7) & ~(size_t)7, ctl_bytes = off_dup + 8 * 32;
+    nsub = std::max<u32>(1, nsub);
+    const size_t off_dup = (64 + 4 * (size_t)nparts * nsub + 7) & ~(size_t)7, ctl_bytes = off_dup + 8 * 32;
     TMP_ALLOC(d_ctl, c, ctl_bytes);
     HIPCHK(hipMemsetAsync(d_ctl.b->p, 0, ctl_bytes, st));
     HIPCHK(hipMemsetAsync(count_out, 0, 4 * (size_t)spp * nparts, st));   // (slots past the last one: nothing)
@@ -2598,6 +2599,7 @@ static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const 
     job.cap2 = rec.cap2;
     job.nslots = rec.nslots;
     job.spp = spp;
+    job.nsub = nsub;
     c->prof_begin(KC_SKM_PACK);
     kh_launch_skm_pack(job, st);
     c->prof_end();
@@ -2610,7 +2612,10 @@ static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const 
         if (soft_done) return KH_OK;
         return kh_fail(KH_E_CAPACITY, "kh_skm_pack: a slot or a part overflowed");
     }
-    for (int p = 0; p < nparts; ++p) part_n[p] = h[16 + p];
+    for (int p = 0; p < nparts; ++p) {   // (with several cursors per part: the records, which then lie with gaps)
+        part_n[p] = 0;
+        for (u32 q = 0; q < nsub; ++q) part_n[p] += h[16 + (size_t)p * nsub + q];
+    }
     if (dup_out) memcpy(dup_out, reinterpret_cast<const u8*>(h.data()) + off_dup, 8 * 32);
     if (soft_done) *soft_done = true;
     return KH_OK;
@@ -2727,7 +2732,7 @@ static int exp1_big_group_skm(kh_ctx* c, int n, const uint8_t* const* seqs, cons
         bool ok = false;
         KHCHK(skm_pack_impl(c, m, seqs + first[p], lens + first[p], on_device, tag.data(), k, nslots, 1, cap, base,
                             reinterpret_cast<u32*>(base + off_mask), reinterpret_cast<u32*>(base + off_count),
-                            reinterpret_cast<u32*>(base + off_off), &part_n, (u32)m, &inst, dup, &ok));
+                            reinterpret_cast<u32*>(base + off_off), &part_n, (u32)m, &inst, dup, &ok, 64));
         if (!ok) {
             if (dbg) fprintf(stderr, "[skm phased] phase %d: the records did not fit\n", p);
             return KH_OK;

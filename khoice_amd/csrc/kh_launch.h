@@ -184,6 +184,8 @@ struct KhSkmPackJob {
     unsigned long long* dup;        // [32] or null: per tag, k-mer instances of records that repeat one of the SAME tag
     u64 part_cap;
     u32 cap2, nslots, spp;          // spp: slots per part (slot s belongs to part s / spp)
+    u32 nsub;                       // cursors per part (slot s uses cursor s % nsub over 1 / nsub of the part's array): 1 = the
+                                    // part is filled without gaps (it travels); more = no single hot atomic (one GPU)
 };
 struct KhSkmPiece {                 // what one source rank sent for this rank's slots
     const uint4* rec;

@@ -1049,12 +1049,16 @@ __global__ __launch_bounds__(SKM_BIG_NT) void k_skm_big(const KhSkmJob jb, u32 c
 //                  folds popcount(mask) into its counter (the high plane) and clears the mask: tags of different
 //                  phases are different groups, so the counter ends as "in how many groups of all ranks".
 // ------------------------------------------------------------------------------------------
-constexpr u32 SKM_PK_NT = 1024, SKM_PK_T = 4096;
-size_t kh_skm_pack_lds_bytes() { return (size_t)SKM_PK_NT * 16 + (size_t)SKM_PK_T * 4 + (size_t)SKM_PK_NT * 4 + 64; }
+// (NT threads = the most records a slot may hold: the host picks 256 / 512 / 1024 from the regions' capacity — a
+// workgroup per slot costs ~5 us whatever it holds, and four or eight of the small ones fit a CU instead of two)
+static size_t skm_pack_lds_bytes(u32 nt) { return (size_t)nt * 16 + (size_t)nt * 4 * 4 + (size_t)nt * 4 + 64; }
+size_t kh_skm_pack_lds_bytes() { return skm_pack_lds_bytes(1024); }
 
-__global__ __launch_bounds__(SKM_PK_NT) void k_skm_pack(const KhSkmPackJob jb) {
+template <u32 NT>
+__global__ __launch_bounds__(NT) void k_skm_pack(const KhSkmPackJob jb) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
-    constexpr u32 NT = SKM_PK_NT, T = SKM_PK_T;
+    constexpr u32 T = 4 * NT, TSH = NT == 1024 ? 20u : (NT == 512 ? 21u : 22u);
+    static_assert(NT == 1024 || NT == 512 || NT == 256, "table of 4 NT entries, a power of two");
     uint4* stage = reinterpret_cast<uint4*>(lds_raw);
     u32* dd = reinterpret_cast<u32*>(lds_raw + (size_t)NT * 16);
     u32* rmask = dd + T;
@@ -1084,7 +1088,7 @@ __global__ __launch_bounds__(SKM_PK_NT) void k_skm_pack(const KhSkmPackJob jb) {
         u32 h = rr.x * 0x9E3779B1u ^ rr.y * 0x85EBCA77u ^ rr.z * 0xC2B2AE3Du ^ (rr.w & ~(63u << 21)) * 0x27D4EB2Fu;
         h ^= h >> 15;
         h *= 0x2C1B3C6Du;
-        u32 hp = h >> 20;
+        u32 hp = h >> TSH;
         bool pend = nj != 0;
         while (__builtin_amdgcn_ballot_w64(pend)) {
             if (pend) {
@@ -1111,14 +1115,17 @@ __global__ __launch_bounds__(SKM_PK_NT) void k_skm_pack(const KhSkmPackJob jb) {
     const u32 nsurv = scratch[0];
     const u32 part = slot / jb.spp;
     if (tid == 0) {
-        const u32 base = nsurv ? atomicAdd(&jb.part_cursor[part], nsurv) : 0u;
+        const u32 sub = slot % jb.nsub;
+        const u64 subcap = jb.part_cap / jb.nsub;
+        u32 base = nsurv ? atomicAdd(&jb.part_cursor[part * jb.nsub + sub], nsurv) : 0u;
+        if ((u64)base + nsurv > subcap) { atomicOr(jb.ctl, KH_ERR_CAPACITY); base = 0; scratch[0] = 0; }
+        base += (u32)(sub * subcap);
         scratch[1] = base;
         jb.slot_count[slot] = nsurv;
         jb.slot_off[slot] = base;
-        if ((u64)base + nsurv > jb.part_cap) atomicOr(jb.ctl, KH_ERR_CAPACITY);
     }
     __syncthreads();
-    if (won) {
+    if (won && scratch[0]) {
         const u64 at = (u64)scratch[1] + wbase + incl - 1u;
         if (at < jb.part_cap) {
             jb.out_rec[(u64)part * jb.part_cap + at] = rr;
@@ -1129,14 +1136,20 @@ __global__ __launch_bounds__(SKM_PK_NT) void k_skm_pack(const KhSkmPackJob jb) {
 
 constexpr u32 SKM_PH_NT = 1024, SKM_PH_T = 4096, SKM_PH_T2 = 128, SKM_PH_MAXCH = 3072, SKM_PH_HBINS = 512;
 constexpr u32 SKM_PH_ROUND = 3072;   // k-mer instances a round of the phased union takes (the table has 4096 entries)
+constexpr u32 SKM_PH_STAGED = 32;    // pieces whose records of a slot are numbered in one go (more: a phase at a time)
 size_t kh_skm_phased_lds_bytes() {
     return (size_t)SKM_PH_T * 16 + (size_t)SKM_PH_T2 * 16 + 128 + (size_t)SKM_PH_HBINS * 4 + (size_t)SKM_PH_MAXCH * 2 +
-           (size_t)KH_SKM_PHASED_MAX_DUP_PIECES * 32 * 4;
+           (size_t)SKM_PH_NT * 2 + (size_t)SKM_PH_STAGED * (8 + 8 + 4 * 4) + 64;
 }
 
+// A slot's time is a chain of memory latencies, not work (a phase holds a few dozen records): the records of ALL
+// pieces are numbered in one go — thread t takes record t of the concatenated pieces, one ordered block scan gives
+// every phase its range of chunks — and the phases that follow only insert and fold (two barriers each).  The
+// per-piece counts and offsets of the NEXT slot are loaded a slot ahead.  A slot with more than 1024 records or
+// 3072 chunks over all pieces (or more than 32 pieces) is numbered a phase at a time instead.
 __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJob jb) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
-    constexpr u32 NT = SKM_PH_NT, T = SKM_PH_T, T2 = SKM_PH_T2, HBITS = 12;
+    constexpr u32 NT = SKM_PH_NT, T = SKM_PH_T, T2 = SKM_PH_T2, HBITS = 12, NP = SKM_PH_STAGED;
     constexpr int E = (int)SKM_UE;
     constexpr u64 EMPTY = ~0ull;
     u8* p = lds_raw;
@@ -1146,10 +1159,16 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
     unsigned long long* okey = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T2 * 8;
     u32* omlo = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
     u32* ocnt = reinterpret_cast<u32*>(p);                                 p += (size_t)T2 * 4;
-    u32* scratch = reinterpret_cast<u32*>(p);                              p += 128;   // [0] chunks of the phase, [1] entries made, [2] k-mers of the slot
+    u32* scratch = reinterpret_cast<u32*>(p);                              p += 128;   // [0] chunks of the phase, [1] entries made, [2] k-mers of the slot, [3] staged?, [8..23] wave totals
     u32* lhist = reinterpret_cast<u32*>(p);                                p += (size_t)SKM_PH_HBINS * 4;
     u16* owner = reinterpret_cast<u16*>(p);                                p += (size_t)SKM_PH_MAXCH * 2;
-    u32* dupc = reinterpret_cast<u32*>(p);                                 // [pieces][32] repeats under one tag (jb.dup)
+    u16* rloc = reinterpret_cast<u16*>(p);                                 p += (size_t)NT * 2;   // staged record t -> piece << 10 | record of the piece's slot
+    const uint4** prec = reinterpret_cast<const uint4**>(p);               p += (size_t)NP * 8;   // the pieces' arrays (loaded once)
+    const u32** pmsk = reinterpret_cast<const u32**>(p);                   p += (size_t)NP * 8;
+    u32* pcnt = reinterpret_cast<u32*>(p);                                 p += (size_t)NP * 4;   // this slot: records per piece,
+    u32* poff = reinterpret_cast<u32*>(p);                                 p += (size_t)NP * 4;   //   where they start,
+    u32* cbeg = reinterpret_cast<u32*>(p);                                 p += (size_t)NP * 4;   //   the piece's chunks [cbeg, cend)
+    u32* cend = reinterpret_cast<u32*>(p);
     const u32 tid0 = threadIdx.x;
     u32 tid = tid0, lane = lane_id();
     const int k = jb.k;
@@ -1158,19 +1177,169 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
     const u32 tsh_sub = tsh_high ? tsh - 32u : tsh;
     const u32 hbins = jb.hist_len < SKM_PH_HBINS ? jb.hist_len : SKM_PH_HBINS;   // counts below this: LDS; above: global atomics
     const bool want_dup = jb.dup != nullptr;
+    const bool staged = jb.npieces <= NP;
+    const u32 npieces = jb.npieces;
     typedef const u32 __attribute__((address_space(4))) * ConstU32;
-    if (want_dup) dupc[tid] = 0;   // (KH_SKM_PHASED_MAX_DUP_PIECES x 32 = the workgroup's 1024 threads)
     if (tid < SKM_PH_HBINS) lhist[tid] = 0;
-    if (tid < 4) scratch[tid] = 0;
+    if (tid < 32) scratch[tid] = 0;
+    const u32* my_count = nullptr;   // thread p < npieces: piece p's per-slot arrays
+    const u32* my_off = nullptr;
+    if (staged && tid < npieces) {
+        const KhSkmPiece pc = jb.pieces[tid];
+        prec[tid] = pc.rec;
+        pmsk[tid] = pc.mask;
+        my_count = pc.count;
+        my_off = pc.off;
+    }
+    u32 nxt_cnt = 0, nxt_off = 0;   // (thread p < npieces) piece p's records of the next slot
+    if (my_count && blockIdx.x < jb.nslots) { nxt_cnt = my_count[blockIdx.x]; nxt_off = my_off[blockIdx.x]; }
     __syncthreads();
+    unsigned long long emptyv = EMPTY;
+    // ---- one chunk: E k-mers of record r0 from its k-mer `first` on, with the genomes / groups `bits`, enter the table
+    auto insert_chunk = [&](const uint4 r0, const u32 bits, const u32 first, const u32 ph, const u32 R, const u32 q, u32& fresh_n) {
+        const u32 left = (r0.w >> 27) - first;
+        const u32 cnt = left < (u32)E ? left : (u32)E;
+        const u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
+        const u32 sh = 2u * first;
+        const u64 lo = sh ? (clo >> sh) | (chi << (64u - sh)) : clo, hi = chi >> sh;
+        const u32 xl = (u32)lo & kml, xh = (u32)(lo >> 32) & kmh;
+        const u64 fw = kh_revpairs64(((u64)xh << 32) | xl) >> fsh;
+        u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl & kml, rh = ~xh & kmh;
+        const u32 t = (u32)((lo >> tsh) | (hi << (64u - tsh)));
+        const u32 tc = ~t;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (e) {
+                fh = __builtin_amdgcn_alignbit(fh, fl, 30) & kmh;
+                fl = ((fl << 2) | ((t >> (2 * e)) & 3u)) & kml;
+                rl = __builtin_amdgcn_alignbit(rh, rl, 2);
+                rh >>= 2;
+                if (tsh_high) rh |= ((tc >> (2 * e)) & 3u) << tsh_sub; else rl |= ((tc >> (2 * e)) & 3u) << tsh_sub;
+            }
+            if ((u32)e >= cnt) break;
+            const bool fwd = fh < rh || (fh == rh && fl < rl);
+            const u32 cl = fwd ? fl : rl, ch = fwd ? fh : rh;
+            const unsigned long long K = ((u64)ch << 32) | cl;
+            const u32 H = key_hash2(cl, ch);
+            if (R != 1 && (((H >> 4) & 0xffffu) * R) >> 16 != q) continue;   // another round's key
+            // main table: KH_TUNE_SKM_FULL_ROUNDS probes, then the second table (8), then the main one to the end
+            u32 S = H >> (32 - HBITS), probes = 0, level = 0;
+            while (true) {
+                unsigned long long* kp = level == 1 ? okey : tkey;
+                const unsigned long long o2 = atomicCAS(&kp[S], emptyv, K);
+                if (o2 == emptyv || o2 == K) {
+                    if (want_dup) {   // uniform: bits set already = a second instance under that tag (rare: global counters)
+                        u32 d = atomicOr((level == 1 ? omlo : tmlo) + S, bits) & bits;
+                        while (d) { atomicAdd(&jb.dup[ph * 32u + (u32)__builtin_ctz(d)], 1ull); d &= d - 1u; }
+                    } else atomicOr((level == 1 ? omlo : tmlo) + S, bits);
+                    if (o2 == emptyv) ++fresh_n;
+                    break;
+                }
+                ++probes;
+                if (level == 0 && probes >= (u32)KH_TUNE_SKM_FULL_ROUNDS) {
+                    level = 1; probes = 0;
+                    S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> (32 - HBITS + 5);
+                } else if (level == 1 && probes >= 8u) {
+                    level = 2; probes = 0;
+                    S = ((H >> (32 - HBITS)) + (u32)KH_TUNE_SKM_FULL_ROUNDS) & (T - 1u);
+                } else if (level == 2 && probes >= T) {
+                    atomicOr(jb.ctl, KH_ERR_CAPACITY);   // the table is full
+                    break;
+                } else {
+                    S = (S + 1u) & (level == 1 ? T2 - 1u : T - 1u);
+                }
+            }
+        }
+    };
+    // ---- behind a phase's insertions: its tags are counted, the mask plane is free for the next phase
+    auto fold = [&](const u32 fresh_n) {
+        if (__builtin_amdgcn_ballot_w64(fresh_n != 0)) {
+            const u32 tot = wave_scan_add(fresh_n);
+            if (lane == KH_WAVE - 1) atomicAdd(&scratch[1], tot);
+        }
+        __syncthreads();
+        uint4 m4 = reinterpret_cast<uint4*>(tmlo)[tid];
+        if (m4.x | m4.y | m4.z | m4.w) {
+            uint4 c4 = reinterpret_cast<uint4*>(tcnt)[tid];
+            c4.x += (u32)__popc(m4.x); c4.y += (u32)__popc(m4.y); c4.z += (u32)__popc(m4.z); c4.w += (u32)__popc(m4.w);
+            reinterpret_cast<uint4*>(tcnt)[tid] = c4;
+            reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (tid < T2) { const u32 m = omlo[tid]; if (m) { ocnt[tid] += (u32)__popc(m); omlo[tid] = 0u; } }
+        if (tid == 0) {
+            scratch[0] = 0;
+            if (scratch[1] > T - T / 16) atomicOr(jb.ctl, KH_ERR_CAPACITY);   // nearly full: probing would crawl
+        }
+        __syncthreads();
+    };
     for (u32 slot = blockIdx.x; slot < jb.nslots; slot += gridDim.x) {
         tid = tid0;
         asm volatile("" : "+v"(tid));   // (addresses formed from it are worked out where they are used)
         lane = tid & (KH_WAVE - 1u);
-        // ---- how many k-mer instances the slot holds over all pieces: more than a table takes -> rounds of key subsets
-        {
+        asm volatile("" : "+v"(emptyv));
+        // ---- the slot's records over all pieces, its k-mer instances (more than a table takes -> rounds of key subsets)
+        bool all_staged = staged;   // uniform
+        u32 my_nj = 0, my_nch = 0, my_cstart = 0, Ctot = 0;
+        if (staged) {
+            if (tid < npieces) {
+                pcnt[tid] = nxt_cnt;
+                poff[tid] = nxt_off;
+                cbeg[tid] = 0;
+                cend[tid] = 0;
+                const u32 ns = slot + gridDim.x;
+                nxt_cnt = 0;
+                if (ns < jb.nslots) { nxt_cnt = my_count[ns]; nxt_off = my_off[ns]; }   // (arrives during this slot)
+            }
+            __syncthreads();
+            u32 acc = 0, myph = NP, myidx = 0, mycnt = 0;
+            for (u32 ph = 0; ph < npieces; ++ph) {
+                const u32 cn = pcnt[ph];
+                if (tid >= acc && tid - acc < cn) { myph = ph; myidx = tid - acc; mycnt = cn; }
+                acc += cn;
+            }
+            if (acc > NT) {
+                all_staged = false;
+                if (tid == 0) atomicMax(jb.ctl + 1, acc);
+            } else {
+                if (myph < NP) {
+                    const u64 at = (u64)poff[myph] + myidx;
+                    my_nj = prec[myph][at].w >> 27;
+                    const u32 touch = pmsk[myph][at];   // (the mask's cache line sets out now)
+                    asm volatile("" ::"v"(touch));
+                    rloc[tid] = (u16)((myph << 10) | myidx);
+                }
+                my_nch = (my_nj + (u32)E - 1u) / (u32)E;
+                // ordered block scan of (chunks, instances): chunk numbers follow the record order, i.e. the phases
+                const u32 both = my_nch | (my_nj << 16);
+                const u32 incl = wave_scan_add(both);
+                if (lane == KH_WAVE - 1) scratch[8 + (tid >> 6)] = incl;
+                __syncthreads();
+                u32 before = 0, total = 0;
+#pragma unroll
+                for (u32 w = 0; w < NT / KH_WAVE; ++w) {
+                    const u32 v = scratch[8 + w];
+                    if (w < (tid >> 6)) before += v;
+                    total += v;
+                }
+                Ctot = total & 0xffffu;
+                my_cstart = ((before + incl - both) & 0xffffu);
+                if (tid == 0) scratch[2] = total >> 16;
+                if (Ctot > SKM_PH_MAXCH) {
+                    all_staged = false;
+                } else if (myph < NP) {
+#pragma unroll
+                    for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
+                        if (cc < my_nch) owner[my_cstart + cc] = (u16)((tid << SKM_OB) | cc);
+                    if (myidx == 0) cbeg[myph] = my_cstart;
+                    if (myidx + 1 == mycnt) cend[myph] = my_cstart + my_nch;
+                }
+            }
+            if (!all_staged && tid == 0) scratch[2] = 0;
+            __syncthreads();
+        }
+        if (!all_staged) {   // instances of the slot, a piece at a time
             u32 mine = 0;
-            for (u32 ph = 0; ph < jb.npieces; ++ph) {
+            for (u32 ph = 0; ph < npieces; ++ph) {
                 const KhSkmPiece pc = jb.pieces[ph];
                 u32 nrec = ((ConstU32)(unsigned long long)pc.count)[slot];
                 nrec = nrec < NT ? nrec : NT;
@@ -1180,8 +1349,8 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
                 const u32 tot = wave_scan_add(mine);
                 if (lane == KH_WAVE - 1) atomicAdd(&scratch[2], tot);
             }
+            __syncthreads();
         }
-        __syncthreads();
         const u32 R = (scratch[2] + SKM_PH_ROUND - 1u) / SKM_PH_ROUND;
         for (u32 q = 0; q < R; ++q) {
             {   // a fresh table (the read-out before it is behind a barrier)
@@ -1190,126 +1359,63 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
                 for (u32 e = 0; e < T / 2 / NT; ++e) k4[e * NT + tid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
                 reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);
                 reinterpret_cast<uint4*>(tcnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
-                unsigned long long e0 = EMPTY;
-                asm volatile("" : "+v"(e0));
-                if (tid < T2) { okey[tid] = e0; omlo[tid] = 0u; ocnt[tid] = 0u; }
+                if (tid < T2) { okey[tid] = emptyv; omlo[tid] = 0u; ocnt[tid] = 0u; }
                 if (tid == 0) { scratch[0] = 0; scratch[1] = 0; }
             }
             __syncthreads();
-            for (u32 ph = 0; ph < jb.npieces; ++ph) {
-                const KhSkmPiece pc = jb.pieces[ph];
-                u32 nrec = ((ConstU32)(unsigned long long)pc.count)[slot];
-                if (!nrec) continue;   // uniform
-                if (nrec > NT) {
-                    if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
-                    nrec = NT;
-                }
-                const u64 roff = ((ConstU32)(unsigned long long)pc.off)[slot];
-                const uint4* __restrict__ rec = pc.rec + roff;
-                const u32* __restrict__ msk = pc.mask + roff;
-                // ---- number the chunks of the phase's records
-                const u32 nj = tid < nrec ? rec[tid].w >> 27 : 0u;
-                const u32 nch = (nj + (u32)E - 1u) / (u32)E;
-                {
-                    const u32 incl = wave_scan_add(nch);
-                    u32 wbase = 0;
-                    if (lane == KH_WAVE - 1 && incl) wbase = atomicAdd(&scratch[0], incl);
-                    wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
-                    const u32 cstart = wbase + incl - nch;
-                    if (cstart + nch <= SKM_PH_MAXCH) {
-#pragma unroll
-                        for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
-                            if (cc < nch) owner[cstart + cc] = (u16)((tid << SKM_OB) | cc);
+            if (all_staged) {
+                for (u32 ph = 0; ph < npieces; ++ph) {
+                    const u32 c0 = cbeg[ph], c1 = cend[ph];
+                    if (c0 == c1) continue;   // uniform
+                    const uint4* __restrict__ rec = prec[ph] + poff[ph];
+                    const u32* __restrict__ msk = pmsk[ph] + poff[ph];
+                    u32 fresh_n = 0;
+                    for (u32 c = c0 + tid; c < c1; c += NT) {
+                        const u32 o = owner[c], ri = rloc[o >> SKM_OB] & 1023u;
+                        insert_chunk(rec[ri], msk[ri], (o & ((1u << SKM_OB) - 1u)) * (u32)E, ph, R, q, fresh_n);
                     }
+                    fold(fresh_n);
                 }
-                __syncthreads();
-                u32 C = scratch[0];
-                if (C > SKM_PH_MAXCH) {
-                    if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
-                    C = 0;
-                }
-                unsigned long long emptyv = EMPTY;
-                asm volatile("" : "+v"(emptyv));
-                u32 fresh_n = 0;   // entries this thread created in this phase
-                for (u32 c = tid; c < C; c += NT) {
-                    const u32 o = owner[c], ri = o >> SKM_OB, first = (o & ((1u << SKM_OB) - 1u)) * (u32)E;
-                    const uint4 r0 = rec[ri];
-                    const u32 bits = msk[ri];
-                    const u32 left = (r0.w >> 27) - first;
-                    const u32 cnt = left < (u32)E ? left : (u32)E;
-                    const u64 clo = ((u64)r0.y << 32) | r0.x, chi = ((u64)r0.w << 32) | r0.z;
-                    const u32 sh = 2u * first;
-                    const u64 lo = sh ? (clo >> sh) | (chi << (64u - sh)) : clo, hi = chi >> sh;
-                    const u32 xl = (u32)lo & kml, xh = (u32)(lo >> 32) & kmh;
-                    const u64 fw = kh_revpairs64(((u64)xh << 32) | xl) >> fsh;
-                    u32 fl = (u32)fw, fh = (u32)(fw >> 32), rl = ~xl & kml, rh = ~xh & kmh;
-                    const u32 t = (u32)((lo >> tsh) | (hi << (64u - tsh)));
-                    const u32 tc = ~t;
+            } else {
+                for (u32 ph = 0; ph < npieces; ++ph) {
+                    const KhSkmPiece pc = jb.pieces[ph];
+                    u32 nrec = ((ConstU32)(unsigned long long)pc.count)[slot];
+                    if (!nrec) continue;   // uniform
+                    if (nrec > NT) {
+                        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                        nrec = NT;
+                    }
+                    const u64 roff = ((ConstU32)(unsigned long long)pc.off)[slot];
+                    const uint4* __restrict__ rec = pc.rec + roff;
+                    const u32* __restrict__ msk = pc.mask + roff;
+                    // ---- number the chunks of the phase's records
+                    const u32 nj = tid < nrec ? rec[tid].w >> 27 : 0u;
+                    const u32 nch = (nj + (u32)E - 1u) / (u32)E;
+                    {
+                        const u32 incl = wave_scan_add(nch);
+                        u32 wbase = 0;
+                        if (lane == KH_WAVE - 1 && incl) wbase = atomicAdd(&scratch[0], incl);
+                        wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
+                        const u32 cstart = wbase + incl - nch;
+                        if (cstart + nch <= SKM_PH_MAXCH) {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        if (e) {
-                            fh = __builtin_amdgcn_alignbit(fh, fl, 30) & kmh;
-                            fl = ((fl << 2) | ((t >> (2 * e)) & 3u)) & kml;
-                            rl = __builtin_amdgcn_alignbit(rh, rl, 2);
-                            rh >>= 2;
-                            if (tsh_high) rh |= ((tc >> (2 * e)) & 3u) << tsh_sub; else rl |= ((tc >> (2 * e)) & 3u) << tsh_sub;
-                        }
-                        if ((u32)e >= cnt) break;
-                        const bool fwd = fh < rh || (fh == rh && fl < rl);
-                        const u32 cl = fwd ? fl : rl, ch = fwd ? fh : rh;
-                        const unsigned long long K = ((u64)ch << 32) | cl;
-                        const u32 H = key_hash2(cl, ch);
-                        if (R != 1 && (((H >> 4) & 0xffffu) * R) >> 16 != q) continue;   // another round's key
-                        // main table: KH_TUNE_SKM_FULL_ROUNDS probes, then the second table (8), then the main one to the end
-                        u32 S = H >> (32 - HBITS), probes = 0, level = 0;
-                        while (true) {
-                            unsigned long long* kp = level == 1 ? okey : tkey;
-                            const unsigned long long o2 = atomicCAS(&kp[S], emptyv, K);
-                            if (o2 == emptyv || o2 == K) {
-                                if (want_dup) {   // uniform: bits set already = a second instance under that tag
-                                    u32 d = atomicOr((level == 1 ? omlo : tmlo) + S, bits) & bits;
-                                    while (d) { atomicAdd(&dupc[ph * 32u + (u32)__builtin_ctz(d)], 1u); d &= d - 1u; }
-                                } else atomicOr((level == 1 ? omlo : tmlo) + S, bits);
-                                if (o2 == emptyv) ++fresh_n;
-                                break;
-                            }
-                            ++probes;
-                            if (level == 0 && probes >= (u32)KH_TUNE_SKM_FULL_ROUNDS) {
-                                level = 1; probes = 0;
-                                S = ((H ^ (H >> 15)) * 0x85EBCA77u) >> (32 - HBITS + 5);
-                            } else if (level == 1 && probes >= 8u) {
-                                level = 2; probes = 0;
-                                S = ((H >> (32 - HBITS)) + (u32)KH_TUNE_SKM_FULL_ROUNDS) & (T - 1u);
-                            } else if (level == 2 && probes >= T) {
-                                atomicOr(jb.ctl, KH_ERR_CAPACITY);   // the table is full
-                                break;
-                            } else {
-                                S = (S + 1u) & (level == 1 ? T2 - 1u : T - 1u);
-                            }
+                            for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
+                                if (cc < nch) owner[cstart + cc] = (u16)((tid << SKM_OB) | cc);
                         }
                     }
-                }
-                if (__builtin_amdgcn_ballot_w64(fresh_n != 0)) {
-                    const u32 tot = wave_scan_add(fresh_n);
-                    if (lane == KH_WAVE - 1) atomicAdd(&scratch[1], tot);
-                }
-                __syncthreads();
-                // ---- fold: the phase's tags are counted, the mask plane is free for the next phase
-                {
-                    uint4 m4 = reinterpret_cast<uint4*>(tmlo)[tid];
-                    if (m4.x | m4.y | m4.z | m4.w) {
-                        uint4 c4 = reinterpret_cast<uint4*>(tcnt)[tid];
-                        c4.x += (u32)__popc(m4.x); c4.y += (u32)__popc(m4.y); c4.z += (u32)__popc(m4.z); c4.w += (u32)__popc(m4.w);
-                        reinterpret_cast<uint4*>(tcnt)[tid] = c4;
-                        reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);
+                    __syncthreads();
+                    u32 C = scratch[0];
+                    if (C > SKM_PH_MAXCH) {
+                        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
+                        C = 0;
                     }
-                    if (tid < T2) { const u32 m = omlo[tid]; if (m) { ocnt[tid] += (u32)__popc(m); omlo[tid] = 0u; } }
-                    if (tid == 0) {
-                        scratch[0] = 0;
-                        if (scratch[1] > T - T / 16) atomicOr(jb.ctl, KH_ERR_CAPACITY);   // nearly full: probing would crawl
+                    u32 fresh_n = 0;   // entries this thread created in this phase
+                    for (u32 c = tid; c < C; c += NT) {
+                        const u32 o = owner[c], ri = o >> SKM_OB;
+                        insert_chunk(rec[ri], msk[ri], (o & ((1u << SKM_OB) - 1u)) * (u32)E, ph, R, q, fresh_n);
                     }
+                    fold(fresh_n);
                 }
-                __syncthreads();
             }
             // ---- every occupied entry is one distinct k-mer of the slot; its counter: in how many (phase, tag) pairs
             {
@@ -1334,11 +1440,10 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
             }
             __syncthreads();
         }
-        if (!R) __syncthreads();   // (an empty slot: scratch[2] is read again only behind the next barrier anyway)
+        if (!R) __syncthreads();   // (an empty slot: scratch[2] is written again only behind the next barrier anyway)
     }
     __syncthreads();
     if (tid0 < hbins && lhist[tid0]) atomicAdd(&jb.hist[tid0], (unsigned long long)lhist[tid0]);
-    if (want_dup && tid0 < jb.npieces * 32u && dupc[tid0]) atomicAdd(&jb.dup[tid0], (unsigned long long)dupc[tid0]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1383,9 +1488,15 @@ void kh_launch_skm_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st) 
 }
 void kh_launch_skm_pack(const KhSkmPackJob& job, hipStream_t st) {
     if (!job.nslots) return;
-    const size_t lds = kh_skm_pack_lds_bytes();
-    skm_allow_lds(k_skm_pack, lds);
-    hipLaunchKernelGGL(k_skm_pack, dim3(job.nslots), dim3(SKM_PK_NT), lds, st, job);
+    if (job.cap2 <= 256) {
+        hipLaunchKernelGGL(k_skm_pack<256>, dim3(job.nslots), dim3(256), skm_pack_lds_bytes(256), st, job);
+    } else if (job.cap2 <= 512) {
+        hipLaunchKernelGGL(k_skm_pack<512>, dim3(job.nslots), dim3(512), skm_pack_lds_bytes(512), st, job);
+    } else {
+        const size_t lds = skm_pack_lds_bytes(1024);
+        skm_allow_lds(k_skm_pack<1024>, lds);
+        hipLaunchKernelGGL(k_skm_pack<1024>, dim3(job.nslots), dim3(1024), lds, st, job);
+    }
 }
 void kh_launch_skm_phased(const KhSkmPhasedJob& job, u32 grid, hipStream_t st) {
     if (!job.nslots || !grid) return;
