@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the two forms of the fused path: for random genome sets (lengths 0 .. 300 kbp, related
-and unrelated genomes, N runs, repeats, low-complexity stretches, 1 .. 90 genomes in 1 .. 12 groups) and random
+and unrelated genomes, N runs, repeats, low-complexity stretches, 1 .. 90 genomes in 1 .. 12 groups, now and
+then two groups of 65 .. 140 genomes) and random
 k in 18 .. 63, kh_exp1_run must give the same histograms and distinct counts in the super-k-mer form and with
 KHOICE_NO_SKM=1 (key arrays).  GPU only, no oracle: python tools/fuzz_forms.py [cases] [seed]"""
 import os, random, sys
@@ -30,10 +31,12 @@ for it in range(cases):
     ngroups = rng.randint(1, 12)
     seqs, group_of = [], []
     shared = dna(rng.randint(0, 3000))
+    big = rng.random() < 0.15          # a case with groups wider than the 64-genome mask (sub-batches / phases)
     for g in range(ngroups):
         L = rng.choice([0, 10, 200, 5000, 40_000, 120_000, 300_000])
+        if big: L = min(L, 40_000)
         anc = dna(L) if L else ""
-        for j in range(rng.randint(1, 9)):
+        for j in range(rng.randint(65, 140) if big and g < 2 and L else rng.randint(1, 9)):
             s = mutate(anc, rng.choice([0.0, 0.001, 0.01, 0.1])) if anc else ""
             r = rng.random()
             if r < 0.15: s += "\n" + shared
