@@ -415,6 +415,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
     using G = SkmUnionGeo<NT, T>;
     constexpr u32 T2 = G::T2, NW = NT / 64;
     constexpr u32 T2SH = T2 == 128 ? 25 : 26;   // 32 - log2(T2)
+    constexpr bool TPOW2 = (T & (T - 1u)) == 0u;   // (a power of two wraps by a mask; 2560 by compare)
     constexpr int E = (int)SKM_UE;
     constexpr u64 EMPTY = ~0ull;   // never a canonical key: the reverse complement of the all-T k-mer is 0
     // Table planes: keys (8-byte stride), low and high halves of the genome masks (4-byte stride).
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
                             }
                             pend = false;
                         } else {
-                            hp = hp + 1u == T ? 0u : hp + 1u;
+                            hp = TPOW2 ? ((hp + 1u) & (T - 1u)) : (hp + 1u == T ? 0u : hp + 1u);
                         }
                     }
                 }
@@ -587,7 +588,8 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
         SKM_MARK("dedup_end");
         SKM_USTAMP(2);
         __syncthreads();   // the staged records and the set of contents are dead, the previous slot's masks are read: the table is made
-        if ((scratch[0] & 0xffffu) > G::MAXCH) {   // uniform, rare: the slot is handed to k_skm_big below; what the merge has counted is taken back
+        const u32 sc0 = scratch[0];   // chunks | k-mers << 16 of the merged records (reset behind the next barrier)
+        if ((sc0 & 0xffffu) > G::MAXCH) {   // uniform, rare: the slot is handed to k_skm_big below; what the merge has counted is taken back
             if (tid < nrec && rmask[tid] == 0u) {
                 const u32 w = stage[tid].w;
                 atomicSub(&dupc[(w >> 21) & 63u], w >> 27);
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
         rr = tid < nrec_next ? (jb.reg2 + (u64)(slot + stride) * cap2)[tid] : make_uint4(0, 0, 0, 0);
         clear_keys();
         clear_masks();
-        u32 C = scratch[0] & 0xffffu, N = scratch[0] >> 16;
+        u32 C = sc0 & 0xffffu, N = sc0 >> 16;
         SKM_USTAMP(3);
         SKM_MARK("after_scan");
         st_full = N > st_full ? N : st_full;
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
                                 act &= ~(1u << e);
                                 if (fresh) mk |= 1u << e;
                             } else {
-                                slot_[e] = slot_[e] + 1u == T ? 0u : slot_[e] + 1u;
+                                slot_[e] = TPOW2 ? ((slot_[e] + 1u) & (T - 1u)) : (slot_[e] + 1u == T ? 0u : slot_[e] + 1u);
                             }
                         }
                     }
@@ -738,12 +740,12 @@ __global__ __launch_bounds__(NT, 8) void k_skm_union(const KhSkmJob jb, u32 cs) 
                                 if (level == 1 && probes >= 8u) {   // a crowded second table: on in the main one
                                     level = 2; probes = 0;
                                     S = (u32)(((u64)H * T) >> 32) + (u32)KH_TUNE_SKM_FULL_ROUNDS;
-                                    S = S >= T ? S - T : S;
+                                    S = TPOW2 ? (S & (T - 1u)) : (S >= T ? S - T : S);
                                 } else if (level == 2 && probes >= T) {
                                     atomicOr(jb.ctl, KH_ERR_CAPACITY);   // cannot happen: a round holds at most T keys
                                     mine = false;
                                 } else {
-                                    S = level == 1 ? ((S + 1u) & (T2 - 1u)) : (S + 1u == T ? 0u : S + 1u);
+                                    S = level == 1 ? ((S + 1u) & (T2 - 1u)) : (TPOW2 ? ((S + 1u) & (T - 1u)) : (S + 1u == T ? 0u : S + 1u));
                                 }
                             }
                         }

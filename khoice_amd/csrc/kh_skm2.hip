@@ -495,7 +495,8 @@ __global__ __launch_bounds__(SKM2_UNT, SKM2_UNT == 1024 ? 8 : 6) void k_skm2_uni
             }
         }
         __syncthreads();
-        if ((scratch[0] & 0xffffu) > SKM2_MAXCH) {   // uniform, rare: the slot goes to k_skm2_big below; what the merge has counted is taken back
+        const u32 sc0 = scratch[0];
+        if ((sc0 & 0xffffu) > SKM2_MAXCH) {   // uniform, rare: the slot goes to k_skm2_big below; what the merge has counted is taken back
             if (tid < nrec && rmask[tid] == 0u) {
                 const u32 w = stage[2 * tid + 1].w;
                 atomicSub(&dupc[rec2_tag(w)], rec2_n(w));
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(SKM2_UNT, SKM2_UNT == 1024 ? 8 : 6) void k_skm2_uni
         if (tid < nrec_next) { const uint4* r = jb.reg2 + ((u64)(slot + stride) * cap2 + tid) * 2; ra = r[0]; rb = r[1]; }
         clear_keys();
         clear_masks();
-        u32 C = scratch[0] & 0xffffu, N = scratch[0] >> 16;
+        u32 C = sc0 & 0xffffu, N = sc0 >> 16;
         st_full = N > st_full ? N : st_full;
         st_exp += N;
         if (C > SKM2_MAXCH) {   // uniform: more chunks than are numbered here: k_skm2_big takes the slot
