@@ -925,7 +925,7 @@ __global__ __launch_bounds__(SKM_BIG_NT) void k_skm_big(const KhSkmJob jb, u32 c
         atomicAdd(&hstripe[((jb.abase + (ng < cs ? ng : cs)) << sshift) + lsel], 1u);
         return false;
     };
-    for (u32 q = 0; q < R; ++q) {
+    for (u32 q = blockIdx.y; q < R; q += gridDim.y) {   // (the rounds are independent: workgroups (slot, y) share them out)
         {
             uint4* k4 = reinterpret_cast<uint4*>(tkey);
 #pragma unroll
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(SKM_BIG_NT) void k_skm_big(const KhSkmJob jb, u32 c
         if (v) atomicAdd(&rep[i], (unsigned long long)v);
     }
     if (tid < (u32)KH_TAG_MAX_OPS && dupc[tid]) atomicAdd(&jb.dup[tid], (unsigned long long)dupc[tid]);
-    if (tid == 0) atomicAdd(jb.ctl + 3, N);
+    if (tid == 0 && blockIdx.y == 0) atomicAdd(jb.ctl + 3, N);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1506,9 +1506,10 @@ void kh_launch_skm_phased(const KhSkmPhasedJob& job, u32 grid, hipStream_t st) {
     skm_allow_lds(k_skm_phased, lds);
     hipLaunchKernelGGL(k_skm_phased, dim3(grid), dim3(SKM_PH_NT), lds, st, job);
 }
+static u32 big_y() { const char* e = getenv("KHOICE_SKM_BIG_Y"); const int v = e ? atoi(e) : 4; return (u32)(v < 1 ? 1 : (v > 16 ? 16 : v)); }
 void kh_launch_skm_big(const KhSkmJob& job, u32 cs, u32 nbig, hipStream_t st) {
     if (!nbig) return;
     const size_t lds = kh_skm_big_lds_bytes();
     skm_allow_lds(k_skm_big, lds);
-    hipLaunchKernelGGL(k_skm_big, dim3(nbig), dim3(SKM_BIG_NT), lds, st, job, cs);
+    hipLaunchKernelGGL(k_skm_big, dim3(nbig, nbig < 2048u ? big_y() : 1u), dim3(SKM_BIG_NT), lds, st, job, cs);   // y: the rounds of a slot side by side
 }

@@ -785,7 +785,7 @@ __global__ __launch_bounds__(SKM2_BIG_NT) void k_skm2_big(const KhSkmJob jb, u32
         atomicAdd(&hstripe[((jb.abase + (ng < cs ? ng : cs)) << sshift) + lsel], 1u);
         return false;
     };
-    for (u32 q = 0; q < R; ++q) {
+    for (u32 q = blockIdx.y; q < R; q += gridDim.y) {   // (the rounds are independent: workgroups (slot, y) share them out)
         for (u32 i = tid; i < T; i += NT) reinterpret_cast<uint4*>(tklo)[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
         for (u32 i = tid; i < T / 2; i += NT) reinterpret_cast<uint4*>(tmlo)[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < T2) { oklo[tid] = EMPTY; okhi[tid] = EMPTY; omlo[tid] = 0u; omhi[tid] = 0u; }
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(SKM2_BIG_NT) void k_skm2_big(const KhSkmJob jb, u32
         if (v) atomicAdd(&rep[i], (unsigned long long)v);
     }
     if (tid < (u32)KH_TAG_MAX_OPS && dupc[tid]) atomicAdd(&jb.dup[tid], (unsigned long long)dupc[tid]);
-    if (tid == 0) atomicAdd(jb.ctl + 3, N);
+    if (tid == 0 && blockIdx.y == 0) atomicAdd(jb.ctl + 3, N);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -941,9 +941,10 @@ void kh_launch_skm2_union(const KhSkmJob& job, u32 cs, u32 grid, hipStream_t st)
     skm2_allow_lds(k_skm2_union, lds);
     hipLaunchKernelGGL(k_skm2_union, dim3(grid), dim3(SKM2_UNT), lds, st, job, cs);
 }
+static u32 big_y() { const char* e = getenv("KHOICE_SKM_BIG_Y"); const int v = e ? atoi(e) : 4; return (u32)(v < 1 ? 1 : (v > 16 ? 16 : v)); }
 void kh_launch_skm2_big(const KhSkmJob& job, u32 cs, u32 nbig, hipStream_t st) {
     if (!nbig) return;
     const size_t lds = kh_skm2_big_lds_bytes();
     skm2_allow_lds(k_skm2_big, lds);
-    hipLaunchKernelGGL(k_skm2_big, dim3(nbig), dim3(SKM2_BIG_NT), lds, st, job, cs);
+    hipLaunchKernelGGL(k_skm2_big, dim3(nbig, nbig < 2048u ? big_y() : 1u), dim3(SKM2_BIG_NT), lds, st, job, cs);   // y: the rounds of a slot side by side
 }
