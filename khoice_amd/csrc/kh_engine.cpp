@@ -1542,7 +1542,10 @@ struct SkmRecords {
     u64 records = 0;            // out: records written
     u32 fan_hint = 0;           // in: genomes whose copies of a locus arrive together (tags of ONE group: the sub-batch size)
     std::vector<u64>* inst = nullptr;   // out (if set): k-mer instances per sequence, in the caller's order
-    ~SkmRecords() { buf_unref(reg2); buf_unref(ws); }
+    bool want_spill = false;    // in: records that did not fit their slot's region are handed out too (else: a failure)
+    DevBuf* spill = nullptr;    // out: [spill_cap] records, then [spill_cap] u32 slots
+    u32 spill_n = 0, spill_cap = 0;
+    ~SkmRecords() { buf_unref(reg2); buf_unref(ws); buf_unref(spill); }
 };
 static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                     const int* group_of, int ngroups, int k, u32 cs, uint64_t* within_hist,
@@ -1819,8 +1822,19 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         u32 h_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(h_ctl, job.ctl, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        // (records on the side list are not part of what is handed out: an overfull slot is a failure here)
-        if ((h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER)) || h_ctl[5]) { c->stat.retries++; return KH_OK; }
+        if (getenv("KHOICE_SKM_DEBUG"))
+            fprintf(stderr, "[skm records] k=%d positions=%llu nb1=%u S=%u nslots=%u cap1 %u cap2 %u | records %u errors %u spilled %u\n", k,
+                    (unsigned long long)total_pos, nb1, S, nslots, cap1, cap2, h_ctl[2], h_ctl[0], h_ctl[5]);
+        // (records on the side list: handed out to a caller that asked for them, a failure otherwise)
+        if ((h_ctl[0] & (KH_ERR_CAPACITY | KH_ERR_ORDER)) || (h_ctl[5] && (!rec_out->want_spill || two || h_ctl[5] > spill_cap))) {
+            c->stat.retries++;
+            return KH_OK;
+        }
+        if (h_ctl[5]) {
+            rec_out->spill = d_spill.b; d_spill.b = nullptr;
+            rec_out->spill_n = h_ctl[5];
+            rec_out->spill_cap = spill_cap;
+        }
         c->stat.skm_records += h_ctl[2];
         if (rec_out->inst) {
             std::vector<u64> hi(nseq);
@@ -2495,7 +2509,7 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
 static bool skm_exchange_k(int k) { return k >= KH_SKM_MIN_K && k <= KH_SKM_MAX_K; }
 
 // slots for `nparts` pieces of at most positions_max k-mer positions each; false: too many k-mers per piece
-static bool skm_exchange_geometry(int k, uint64_t positions_max, int nparts, u64* nslots, double* per_kmer_out) {
+static bool skm_exchange_geometry(int k, uint64_t positions_max, int nparts, u32 fan, u64* nslots, double* per_kmer_out) {
     const int m15w = k - 15 + 1;
     int m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;
     if (k < 20) m = std::max(11, k - 6);
@@ -2509,11 +2523,17 @@ static bool skm_exchange_geometry(int k, uint64_t positions_max, int nparts, u64
     // 2600 / (0.55 x nparts) per rank keeps the owner at one round (unrelated genomes: two).  A rank's slot must also
     // fit the pack kernel's 1024 records, and the two partition levels give 512 x 512 slots at most (beyond: the
     // slots grow and the owner takes more rounds).
+    // The regions of a rank's slots are sized as exp1_skm sizes them: the mean with the slack of five sigma, where the
+    // `fan` genomes of a group bring their copies of a locus together (at least 1.7): that must stay below the pack
+    // kernel's 1024 records.
+    const double clump = 0.5 * (double)(w + 1) * (double)std::max<u32>(1, fan);
+    auto region = [&](double mean) { return mean * per_kmer * std::max(1.7, 1.0 + 5.0 * std::sqrt(clump / mean)) + 128.0; };
     double mean = std::min(2600.0 / (0.55 * (double)nparts), (1024.0 - 128.0) / (1.7 * per_kmer));
+    while (mean > 64.0 && region(mean) > 1008.0) mean *= 0.95;
     if (const char* e = getenv("KHOICE_SKM_EXCHANGE_MEAN")) mean = std::max(16.0, atof(e));   // tests: rounds on the owner
     u64 ns = std::max<u64>((u64)nparts, (u64)((double)std::max<u64>(1, positions_max) / mean) + 1);
     ns = std::min<u64>(ns, (u64)KH_SKM2_MAX_COARSE * KH_SKM_MAX_FINE);
-    if ((double)positions_max / (double)ns * per_kmer * 1.7 + 128.0 > 1024.0) return false;
+    if (region((double)positions_max / (double)ns) > 1024.0) return false;
     *nslots = ns;
     *per_kmer_out = per_kmer;
     return true;
@@ -2522,10 +2542,9 @@ extern "C" int kh_skm_exchange_plan(kh_ctx* c, int k, uint64_t positions_max, ui
                                     uint32_t* slots_per_part, uint64_t* part_cap) {
     if (!c || !nslots || !slots_per_part || !part_cap || nparts < 1) return kh_fail(KH_E_ARG, "kh_skm_exchange_plan: bad argument");
     if (!skm_exchange_k(k)) return kh_fail(KH_E_ARG, "the exchange form takes k = %d .. %d", KH_SKM_MIN_K, KH_SKM_MAX_K);
-    (void)fan_max;
     u64 ns = 0;
     double per_kmer = 0;
-    if (!skm_exchange_geometry(k, positions_max, nparts, &ns, &per_kmer))
+    if (!skm_exchange_geometry(k, positions_max, nparts, fan_max, &ns, &per_kmer))
         return kh_fail(KH_E_CAPACITY, "too many k-mers per rank for the exchange form (%llu positions)", (unsigned long long)positions_max);
     *nslots = (u32)ns;
     *slots_per_part = (u32)((ns + nparts - 1) / nparts);
@@ -2539,7 +2558,8 @@ extern "C" int kh_skm_exchange_plan(kh_ctx* c, int k, uint64_t positions_max, ui
 static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                          const int* tag_of, int k, uint32_t nslots, int nparts, uint64_t part_cap, void* rec_out,
                          uint32_t* mask_out, uint32_t* count_out, uint32_t* off_out, uint64_t* part_n, u32 fan_hint,
-                         std::vector<u64>* inst_out, u64* dup_out /* [32] host */, bool* soft_done, u32 nsub = 1);
+                         std::vector<u64>* inst_out, u64* dup_out /* [32] host */, bool* soft_done, u32 nsub = 1,
+                         SkmRecords* keep = nullptr /* the caller's: asks for and receives the side list */);
 extern "C" int kh_skm_pack(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                            const int* tag_of, int k, uint32_t nslots, int nparts, uint64_t part_cap, void* rec_out,
                            uint32_t* mask_out, uint32_t* count_out, uint32_t* off_out, uint64_t* part_n) {
@@ -2549,7 +2569,7 @@ extern "C" int kh_skm_pack(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
 static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint64_t* lens, int on_device,
                          const int* tag_of, int k, uint32_t nslots, int nparts, uint64_t part_cap, void* rec_out,
                          uint32_t* mask_out, uint32_t* count_out, uint32_t* off_out, uint64_t* part_n, u32 fan_hint,
-                         std::vector<u64>* inst_out, u64* dup_out, bool* soft_done, u32 nsub) {
+                         std::vector<u64>* inst_out, u64* dup_out, bool* soft_done, u32 nsub, SkmRecords* keep) {
     if (soft_done) *soft_done = false;
     if (!c || !seqs || !lens || !tag_of || nseq <= 0 || nparts < 1 || !rec_out || !mask_out || !count_out || !off_out || !part_n)
         return kh_fail(KH_E_ARG, "kh_skm_pack: bad argument");
@@ -2561,10 +2581,12 @@ static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const 
     }
     HIPCHK(hipSetDevice(c->dev));
     hipStream_t st = c->st;
-    SkmRecords rec;
+    SkmRecords own;
+    SkmRecords& rec = keep ? *keep : own;
     rec.force_slots = nslots;
     rec.fan_hint = fan_hint;
     rec.inst = inst_out;
+    rec.want_spill = keep != nullptr;
     bool done = false;
     {   // every tag needs a sequence for the geometry code (groups without genomes are refused there): tags are dense here
         std::vector<int> seen(ntags, 0);
@@ -2623,7 +2645,8 @@ static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const 
 
 static int skm_phased_impl(kh_ctx* c, int k, int npieces, const void* const* recs, const uint32_t* const* masks,
                            const uint32_t* const* counts, const uint32_t* const* offs, uint32_t nslots, uint32_t cs,
-                           uint64_t* hist, uint32_t hist_len, u64* dup_out /* [npieces][32] host or null */, bool* soft_done);
+                           uint64_t* hist, uint32_t hist_len, u64* dup_out /* [npieces][32] host or null */, bool* soft_done,
+                           const u32* dup_row = nullptr, const u32* join_next = nullptr);
 extern "C" int kh_skm_phased_histogram(kh_ctx* c, int k, int npieces, const void* const* recs, const uint32_t* const* masks,
                                        const uint32_t* const* counts, const uint32_t* const* offs, uint32_t nslots, uint32_t cs,
                                        uint64_t* hist, uint32_t hist_len) {
@@ -2631,11 +2654,10 @@ extern "C" int kh_skm_phased_histogram(kh_ctx* c, int k, int npieces, const void
 }
 static int skm_phased_impl(kh_ctx* c, int k, int npieces, const void* const* recs, const uint32_t* const* masks,
                            const uint32_t* const* counts, const uint32_t* const* offs, uint32_t nslots, uint32_t cs,
-                           uint64_t* hist, uint32_t hist_len, u64* dup_out, bool* soft_done) {
+                           uint64_t* hist, uint32_t hist_len, u64* dup_out, bool* soft_done, const u32* dup_row, const u32* join_next) {
     if (soft_done) *soft_done = false;
     if (!c || npieces < 1 || !recs || !masks || !counts || !offs || !hist || hist_len < 2 || cs < 1)
         return kh_fail(KH_E_ARG, "kh_skm_phased_histogram: bad argument");
-    if (dup_out && npieces > (int)KH_SKM_PHASED_MAX_DUP_PIECES) return kh_fail(KH_E_ARG, "kh_skm_phased_histogram: too many pieces");
     if (!skm_exchange_k(k)) return kh_fail(KH_E_ARG, "the exchange form takes k = %d .. %d", KH_SKM_MIN_K, KH_SKM_MAX_K);
     HIPCHK(hipSetDevice(c->dev));
     hipStream_t st = c->st;
@@ -2650,6 +2672,8 @@ static int skm_phased_impl(kh_ctx* c, int k, int npieces, const void* const* rec
         hp[i].mask = masks[i];
         hp[i].count = counts[i];
         hp[i].off = offs[i];
+        hp[i].dup_row = dup_row ? dup_row[i] : (u32)i;
+        hp[i].join_next = join_next ? join_next[i] : 0u;
     }
     HIPCHK(hipMemsetAsync(d_ws.b->p, 0, ws_bytes, st));
     HIPCHK(hipMemcpyAsync(d_ws.b->p, up.data(), off_hist, hipMemcpyHostToDevice, st));
@@ -2706,7 +2730,7 @@ static int exp1_big_group_skm(kh_ctx* c, int n, const uint8_t* const* seqs, cons
     u64 ns = 0;
     double per_kmer = 0;
     const bool dbg = getenv("KHOICE_SKM_DEBUG") != nullptr;
-    if (!skm_exchange_geometry(k, pos_max, P, &ns, &per_kmer)) {
+    if (!skm_exchange_geometry(k, pos_max, P, (u32)SUB, &ns, &per_kmer)) {
         if (dbg) fprintf(stderr, "[skm phased] %d genomes in %d phases: no geometry for %llu positions per phase\n", n, P, (unsigned long long)pos_max);
         return KH_OK;
     }
@@ -2714,9 +2738,11 @@ static int exp1_big_group_skm(kh_ctx* c, int n, const uint8_t* const* seqs, cons
     if (dbg) fprintf(stderr, "[skm phased] %d genomes in %d phases, %u slots, %.0f positions per slot and phase\n", n, P, nslots, (double)pos_max / nslots);
     HIPCHK(hipSetDevice(c->dev));
     std::vector<std::unique_ptr<Tmp>> bufs;
-    std::vector<const void*> recs(P);
-    std::vector<const uint32_t*> masks(P), counts(P), offs(P);
+    std::vector<const void*> recs;
+    std::vector<const uint32_t*> masks, counts, offs;
+    std::vector<u32> rows, joins;   // per piece: the sub-batch it belongs to, "the next piece goes on in the same phase"
     std::vector<u64> inst_all(n, 0), dup_all(n, 0);
+    hipStream_t st = c->st;
     for (int p = 0; p < P; ++p) {
         const int m = first[p + 1] - first[p];
         const u64 cap = ((u64)((double)pos[p] * per_kmer * 1.3) + 8192 + 63) & ~63ull;
@@ -2730,23 +2756,86 @@ static int exp1_big_group_skm(kh_ctx* c, int n, const uint8_t* const* seqs, cons
         std::vector<u64> inst;
         u64 dup[32], part_n = 0;
         bool ok = false;
+        SkmRecords keep;
         KHCHK(skm_pack_impl(c, m, seqs + first[p], lens + first[p], on_device, tag.data(), k, nslots, 1, cap, base,
                             reinterpret_cast<u32*>(base + off_mask), reinterpret_cast<u32*>(base + off_count),
-                            reinterpret_cast<u32*>(base + off_off), &part_n, (u32)m, &inst, dup, &ok, 64));
+                            reinterpret_cast<u32*>(base + off_off), &part_n, (u32)m, &inst, dup, &ok, 64, &keep));
         if (!ok) {
             if (dbg) fprintf(stderr, "[skm phased] phase %d: the records did not fit\n", p);
             return KH_OK;
         }
-        if (dbg) fprintf(stderr, "[skm phased] phase %d: %llu records travel (cap %llu)\n", p, (unsigned long long)part_n, (unsigned long long)cap);
-        recs[p] = base;
-        masks[p] = reinterpret_cast<const u32*>(base + off_mask);
-        counts[p] = reinterpret_cast<const u32*>(base + off_count);
-        offs[p] = reinterpret_cast<const u32*>(base + off_off);
+        if (dbg) fprintf(stderr, "[skm phased] phase %d: %llu records travel (cap %llu), %u on the side list\n", p, (unsigned long long)part_n,
+                         (unsigned long long)cap, keep.spill_n);
+        recs.push_back(base);
+        masks.push_back(reinterpret_cast<const u32*>(base + off_mask));
+        counts.push_back(reinterpret_cast<const u32*>(base + off_count));
+        offs.push_back(reinterpret_cast<const u32*>(base + off_off));
+        rows.push_back((u32)p);
+        joins.push_back(0);
         for (int j = 0; j < m; ++j) { inst_all[first[p] + j] = inst[j]; dup_all[first[p] + j] = dup[j]; }
+        if (keep.spill_n) {
+            // Overfull slots (low-complexity sequence): what the regions could not hold is on the side list, unmerged and
+            // in no order.  It joins the sub-batch's phase as extra pieces — sorted by slot on the host (rare, small),
+            // at most 1024 records of a slot per piece.
+            const u32 ns = keep.spill_n;
+            std::vector<uint4> hrec(ns);
+            std::vector<u32> hslot(ns), order(ns);
+            HIPCHK(hipMemcpyAsync(hrec.data(), keep.spill->p, 16 * (size_t)ns, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(hslot.data(), static_cast<const u8*>(keep.spill->p) + 16 * (size_t)keep.spill_cap, 4 * (size_t)ns,
+                                  hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (u32 i = 0; i < ns; ++i) {
+                order[i] = i;
+                if (hslot[i] >= nslots) return kh_fail(KH_E_INTERNAL, "side list: slot %u of %u", hslot[i], nslots);
+            }
+            std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return hslot[a] < hslot[b]; });
+            std::vector<u32> run(nslots, 0);
+            u32 longest = 0;
+            for (u32 i = 0; i < ns; ++i) longest = std::max(longest, ++run[hslot[i]]);
+            const u32 extra = (longest + 1023u) / 1024u;
+            joins.back() = 1;
+            for (u32 e = 0; e < extra; ++e) {
+                std::vector<uint4> prec;
+                std::vector<u32> pmask, pcount(nslots, 0), poff(nslots, 0);
+                for (u32 i = 0; i < ns;) {   // the sorted list, a slot's run at a time
+                    const u32 sl = hslot[order[i]], len = run[sl];
+                    const u32 lo = std::min(len, e * 1024u), hi = std::min(len, (e + 1) * 1024u);
+                    poff[sl] = (u32)prec.size();
+                    pcount[sl] = hi - lo;
+                    for (u32 j = lo; j < hi; ++j) {
+                        const uint4 r = hrec[order[i + j]];
+                        prec.push_back(r);
+                        pmask.push_back(1u << ((r.w >> 21) & 31u));
+                    }
+                    i += len;
+                }
+                const size_t nrec_e = std::max<size_t>(1, prec.size());
+                const size_t e_mask = 16 * nrec_e, e_count = e_mask + ((4 * nrec_e + 15) & ~(size_t)15), e_off = e_count + 4 * (size_t)((nslots + 3) & ~3u),
+                             e_bytes = e_off + 4 * (size_t)((nslots + 3) & ~3u);
+                bufs.emplace_back(new Tmp);
+                TMP_ALLOC(*bufs.back(), c, e_bytes);
+                u8* eb = bufs.back()->as<u8>();
+                if (!prec.empty()) {
+                    HIPCHK(hipMemcpyAsync(eb, prec.data(), 16 * prec.size(), hipMemcpyHostToDevice, st));
+                    HIPCHK(hipMemcpyAsync(eb + e_mask, pmask.data(), 4 * pmask.size(), hipMemcpyHostToDevice, st));
+                }
+                HIPCHK(hipMemcpyAsync(eb + e_count, pcount.data(), 4 * (size_t)nslots, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(eb + e_off, poff.data(), 4 * (size_t)nslots, hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));   // (the host vectors go out of scope)
+                recs.push_back(eb);
+                masks.push_back(reinterpret_cast<const u32*>(eb + e_mask));
+                counts.push_back(reinterpret_cast<const u32*>(eb + e_count));
+                offs.push_back(reinterpret_cast<const u32*>(eb + e_off));
+                rows.push_back((u32)p);
+                joins.push_back(e + 1 < extra ? 1u : 0u);
+            }
+            c->stat.big_slots += (u64)std::count_if(run.begin(), run.end(), [](u32 v) { return v != 0; });
+        }
     }
-    std::vector<u64> pdup((size_t)P * 32, 0), hist(hist_len, 0);
+    std::vector<u64> pdup((size_t)recs.size() * 32, 0), hist(hist_len, 0);
     bool ok = false;
-    KHCHK(skm_phased_impl(c, k, P, recs.data(), masks.data(), counts.data(), offs.data(), nslots, cs, hist.data(), hist_len, pdup.data(), &ok));
+    KHCHK(skm_phased_impl(c, k, (int)recs.size(), recs.data(), masks.data(), counts.data(), offs.data(), nslots, cs, hist.data(), hist_len,
+                          pdup.data(), &ok, rows.data(), joins.data()));
     if (!ok) {
         if (dbg) fprintf(stderr, "[skm phased] the phased union overflowed\n");
         return KH_OK;

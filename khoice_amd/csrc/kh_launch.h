@@ -192,6 +192,8 @@ struct KhSkmPiece {                 // what one source rank sent for this rank's
     const u32* mask;
     const u32* count;               // [nslots of this rank]
     const u32* off;                 // [nslots of this rank] first record of the slot in `rec`
+    u32 dup_row;                    // row of KhSkmPhasedJob::dup its tags count into
+    u32 join_next;                  // 1: the next piece continues this phase (the same tags: no fold in between)
 };
 struct KhSkmPhasedJob {
     const KhSkmPiece* pieces;       // device array [npieces]

@@ -1141,7 +1141,7 @@ constexpr u32 SKM_PH_ROUND = 3072;   // k-mer instances a round of the phased un
 constexpr u32 SKM_PH_STAGED = 32;    // pieces whose records of a slot are numbered in one go (more: a phase at a time)
 size_t kh_skm_phased_lds_bytes() {
     return (size_t)SKM_PH_T * 16 + (size_t)SKM_PH_T2 * 16 + 128 + (size_t)SKM_PH_HBINS * 4 + (size_t)SKM_PH_MAXCH * 2 +
-           (size_t)SKM_PH_NT * 2 + (size_t)SKM_PH_STAGED * (8 + 8 + 4 * 4) + 64;
+           (size_t)SKM_PH_NT * 2 + (size_t)SKM_PH_STAGED * (8 + 8 + 4 * 5) + 64;
 }
 
 // A slot's time is a chain of memory latencies, not work (a phase holds a few dozen records): the records of ALL
@@ -1170,7 +1170,8 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
     u32* pcnt = reinterpret_cast<u32*>(p);                                 p += (size_t)NP * 4;   // this slot: records per piece,
     u32* poff = reinterpret_cast<u32*>(p);                                 p += (size_t)NP * 4;   //   where they start,
     u32* cbeg = reinterpret_cast<u32*>(p);                                 p += (size_t)NP * 4;   //   the piece's chunks [cbeg, cend)
-    u32* cend = reinterpret_cast<u32*>(p);
+    u32* cend = reinterpret_cast<u32*>(p);                                 p += (size_t)NP * 4;
+    u32* pflag = reinterpret_cast<u32*>(p);                                // dup_row << 1 | join_next
     const u32 tid0 = threadIdx.x;
     u32 tid = tid0, lane = lane_id();
     const int k = jb.k;
@@ -1190,6 +1191,7 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
         const KhSkmPiece pc = jb.pieces[tid];
         prec[tid] = pc.rec;
         pmsk[tid] = pc.mask;
+        pflag[tid] = (pc.dup_row << 1) | (pc.join_next & 1u);
         my_count = pc.count;
         my_off = pc.off;
     }
@@ -1254,11 +1256,13 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
         }
     };
     // ---- behind a phase's insertions: its tags are counted, the mask plane is free for the next phase
-    auto fold = [&](const u32 fresh_n) {
+    auto count_fresh = [&](const u32 fresh_n) {
         if (__builtin_amdgcn_ballot_w64(fresh_n != 0)) {
             const u32 tot = wave_scan_add(fresh_n);
             if (lane == KH_WAVE - 1) atomicAdd(&scratch[1], tot);
         }
+    };
+    auto fold_now = [&]() {
         __syncthreads();
         uint4 m4 = reinterpret_cast<uint4*>(tmlo)[tid];
         if (m4.x | m4.y | m4.z | m4.w) {
@@ -1362,61 +1366,69 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
                 reinterpret_cast<uint4*>(tmlo)[tid] = make_uint4(0u, 0u, 0u, 0u);
                 reinterpret_cast<uint4*>(tcnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
                 if (tid < T2) { okey[tid] = emptyv; omlo[tid] = 0u; ocnt[tid] = 0u; }
-                if (tid == 0) { scratch[0] = 0; scratch[1] = 0; }
+                if (tid == 0) { scratch[0] = 0; scratch[1] = 0; scratch[3] = 0; }
             }
             __syncthreads();
+            // A phase = a piece and the pieces joined to it (join_next: the same tags — a sub-batch's side list): the fold
+            // comes behind the last of them that holds records of this slot.
+            bool open = false;   // uniform: insertions since the last fold
             if (all_staged) {
                 for (u32 ph = 0; ph < npieces; ++ph) {
-                    const u32 c0 = cbeg[ph], c1 = cend[ph];
-                    if (c0 == c1) continue;   // uniform
-                    const uint4* __restrict__ rec = prec[ph] + poff[ph];
-                    const u32* __restrict__ msk = pmsk[ph] + poff[ph];
-                    u32 fresh_n = 0;
-                    for (u32 c = c0 + tid; c < c1; c += NT) {
-                        const u32 o = owner[c], ri = rloc[o >> SKM_OB] & 1023u;
-                        insert_chunk(rec[ri], msk[ri], (o & ((1u << SKM_OB) - 1u)) * (u32)E, ph, R, q, fresh_n);
+                    const u32 c0 = cbeg[ph], c1 = cend[ph], fl = pflag[ph];
+                    if (c0 != c1) {   // uniform
+                        const uint4* __restrict__ rec = prec[ph] + poff[ph];
+                        const u32* __restrict__ msk = pmsk[ph] + poff[ph];
+                        u32 fresh_n = 0;
+                        for (u32 c = c0 + tid; c < c1; c += NT) {
+                            const u32 o = owner[c], ri = rloc[o >> SKM_OB] & 1023u;
+                            insert_chunk(rec[ri], msk[ri], (o & ((1u << SKM_OB) - 1u)) * (u32)E, fl >> 1, R, q, fresh_n);
+                        }
+                        count_fresh(fresh_n);
+                        open = true;
                     }
-                    fold(fresh_n);
+                    if (open && !((fl & 1u) && ph + 1 < npieces)) { fold_now(); open = false; }
                 }
             } else {
+                constexpr u32 BATCH = SKM_PH_MAXCH >> SKM_OB;   // records numbered at a time: their chunks fit the owner table
+                u32 par = 0;
                 for (u32 ph = 0; ph < npieces; ++ph) {
                     const KhSkmPiece pc = jb.pieces[ph];
                     u32 nrec = ((ConstU32)(unsigned long long)pc.count)[slot];
-                    if (!nrec) continue;   // uniform
-                    if (nrec > NT) {
+                    if (nrec > NT) {   // uniform
                         if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
                         nrec = NT;
                     }
                     const u64 roff = ((ConstU32)(unsigned long long)pc.off)[slot];
                     const uint4* __restrict__ rec = pc.rec + roff;
                     const u32* __restrict__ msk = pc.mask + roff;
-                    // ---- number the chunks of the phase's records
-                    const u32 nj = tid < nrec ? rec[tid].w >> 27 : 0u;
-                    const u32 nch = (nj + (u32)E - 1u) / (u32)E;
-                    {
-                        const u32 incl = wave_scan_add(nch);
-                        u32 wbase = 0;
-                        if (lane == KH_WAVE - 1 && incl) wbase = atomicAdd(&scratch[0], incl);
-                        wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
-                        const u32 cstart = wbase + incl - nch;
-                        if (cstart + nch <= SKM_PH_MAXCH) {
+                    for (u32 b0 = 0; b0 < nrec; b0 += BATCH) {
+                        // ---- number the chunks of the batch's records
+                        const u32 nj = tid < BATCH && b0 + tid < nrec ? rec[b0 + tid].w >> 27 : 0u;
+                        const u32 nch = (nj + (u32)E - 1u) / (u32)E;
+                        if (__builtin_amdgcn_ballot_w64(nch != 0)) {
+                            const u32 incl = wave_scan_add(nch);
+                            u32 wbase = 0;
+                            if (lane == KH_WAVE - 1 && incl) wbase = atomicAdd(&scratch[par], incl);
+                            wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
+                            const u32 cstart = wbase + incl - nch;
 #pragma unroll
                             for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
                                 if (cc < nch) owner[cstart + cc] = (u16)((tid << SKM_OB) | cc);
                         }
+                        __syncthreads();
+                        const u32 C = scratch[par];   // (<= BATCH << SKM_OB = SKM_PH_MAXCH)
+                        par ^= 3u;                    // the batches' chunk counters alternate: [0] and [3]
+                        if (tid == 0) scratch[par] = 0;   // (the next batch's: nobody reads it before the barrier below)
+                        u32 fresh_n = 0;   // entries this thread created
+                        for (u32 c = tid; c < C; c += NT) {
+                            const u32 o = owner[c], ri = b0 + (o >> SKM_OB);
+                            insert_chunk(rec[ri], msk[ri], (o & ((1u << SKM_OB) - 1u)) * (u32)E, pc.dup_row, R, q, fresh_n);
+                        }
+                        count_fresh(fresh_n);
+                        open = true;
+                        __syncthreads();   // the owner table is written again
                     }
-                    __syncthreads();
-                    u32 C = scratch[0];
-                    if (C > SKM_PH_MAXCH) {
-                        if (tid == 0) atomicOr(jb.ctl, KH_ERR_CAPACITY);
-                        C = 0;
-                    }
-                    u32 fresh_n = 0;   // entries this thread created in this phase
-                    for (u32 c = tid; c < C; c += NT) {
-                        const u32 o = owner[c], ri = o >> SKM_OB;
-                        insert_chunk(rec[ri], msk[ri], (o & ((1u << SKM_OB) - 1u)) * (u32)E, ph, R, q, fresh_n);
-                    }
-                    fold(fresh_n);
+                    if (open && !((pc.join_next & 1u) && ph + 1 < npieces)) { fold_now(); open = false; }
                 }
             }
             // ---- every occupied entry is one distinct k-mer of the slot; its counter: in how many (phase, tag) pairs

@@ -253,6 +253,72 @@ def test_groups_of_more_than_64_genomes_stay_fused(eng, k):
     assert (got3["within_hist"] == want3["within_hist"]).all() and (got3["across_hist"] == want3["across_hist"]).all()
 
 
+@pytest.mark.parametrize("k", [19, 31])
+def test_big_group_edge_genomes(eng, k):
+    """A group of 100 genomes (four phases of the phased union) with the genomes an ingest can hand over: empty ones,
+    one shorter than k, exact copies of another genome (whole records repeat under different tags), a genome that
+    holds its own sequence twice (every k-mer a repeat under ONE tag: counted at the merge), homopolymer and
+    dinucleotide runs (repeats found at the insertion), runs of N; next to it a group of 66, two small ones and a group
+    of 70 genomes full of copies of one insertion sequence (overfull slots: the side list joins the phases).
+    Histograms and distinct counts equal the C restatement's and the phased form did the work."""
+    from oracle import c_oracle as CO
+    from khoice_amd import synth
+    rng = np.random.default_rng(11)
+    anc = synth.ancestor(3, 30_000)
+    base = [synth.clean_text(synth.genome_records(3, j, 30_000, anc)) for j in range(100)]
+    sep = b"\n"          # cleaned text: records joined by a newline
+    g0 = list(base)
+    g0[3] = b""
+    g0[40] = b""
+    g0[7] = base[7][: k - 1]
+    g0[10] = base[9]                                  # an exact copy of its neighbour
+    g0[50] = base[50] + sep + base[50]                # itself twice
+    g0[60] = base[60] + sep + b"A" * 3000 + sep + b"AC" * 2000
+    g0[61] = base[61][:5000] + b"N" * 100 + base[61][5000:]
+    g0[99] = b"T" * 500
+    anc2 = synth.ancestor(4, 20_000)
+    g1 = [synth.clean_text(synth.genome_records(4, j, 20_000, anc2)) for j in range(66)]
+    g2 = [synth.clean_text(synth.genome_records(5, j, 10_000, synth.ancestor(5, 10_000))) for j in range(3)]
+    g3 = [base[0], g1[0]]                             # a small group sharing with both big ones
+    seqs = g0 + g1 + g2 + g3
+    group_of = [0] * len(g0) + [1] * len(g1) + [2] * len(g2) + [3] * len(g3)
+    if k == 31:
+        # a group whose genomes hold 20 copies of an insertion sequence and a tandem repeat: a slot gets 24 x 20 copies
+        # of the same records, above its region -> the side list joins the sub-batch's phase as extra pieces (with
+        # windows of 7 at k = 19 the same records overflow the COARSE regions of so small an input: the call would
+        # fall back as a whole)
+        is_seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=600).tobytes())
+        anc4 = synth.ancestor(6, 40_000)
+        g4 = []
+        for j in range(70):
+            t = synth.clean_text(synth.genome_records(6, j, 40_000, anc4))
+            g4.append(t + sep + sep.join([is_seq] * 20) + sep + b"ACGTTGCA" * 25)
+        seqs += g4
+        group_of += [4] * len(g4)
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    group_of = [group_of[i] for i in order]
+    eng.profile(True)
+    eng.stats_reset()
+    got = eng.exp1_run(seqs, group_of, k, cs=5000, hist_len=300)
+    st = eng.stats()
+    eng.profile(False)
+    want = CO.exp1(seqs, group_of, k, cs=5000, hist_len=300, nthreads=8)
+    assert (got["distinct_per_seq"] == want["distinct_per_seq"]).all()
+    assert (got["within_hist"] == want["within_hist"]).all()
+    assert (got["across_hist"] == want["across_hist"]).all()
+    kern = st["kernels"]
+    big = 3 if k == 31 else 2
+    assert kern["skm_phased"]["launches"] == big and kern["skm_pack"]["launches"] == 4 + 3 * (big - 1), kern
+    assert kern["union_tagged"]["launches"] == 0 and st["retries"] == 0, st
+    if k == 31:
+        assert st["big_slots"] > 0   # overfull slots: through the side list (in the phases, and in the pass by group)
+    # the same with a saturation value below the group sizes
+    got2 = eng.exp1_run(seqs, group_of, k, cs=7, hist_len=9)
+    want2 = CO.exp1(seqs, group_of, k, cs=7, hist_len=9, nthreads=8)
+    assert (got2["within_hist"] == want2["within_hist"]).all() and (got2["across_hist"] == want2["across_hist"]).all()
+
+
 def test_configs3_twenty_groups_on_one_gpu(eng):
     """BASELINE configs[3]'s workload (20 species x 5 genomes x 5 Mbp, k = 31) through kh_exp1_run on ONE GPU: 100 genomes
     = batches of whole groups + the pass by group.  What stays unmeasured for that config is the 8-way sharding."""
