@@ -334,13 +334,17 @@ def across_groups_auto(ops, group_sets: Sequence, k: int, cs: int, hist_len: int
     return across_groups_distributed(ops, group_sets, k, cs, hist_len, group)
 
 
-def across_records_exchange(ops, eng, seqs, group_of: Sequence[int], k: int, cs: int, hist_len: int, group=None) -> np.ndarray:
+def across_records_exchange(ops, eng, seqs, group_of: Sequence[int], k: int, cs: int, hist_len: int, group=None,
+                            overlap=None):
     """Global step_8 histogram by exchange of MINIMIZER RECORDS (SURVEY.md §8e.2 in the super-k-mer form): slots are a
     global function of the minimizer, so rank j owns a range of slots.  Every rank packs its genomes' records (tag =
     local group, identical records merged) by owner, the packed arrays travel in four all-to-alls (records, masks, and
     per slot how many / where), the owner runs one phased union over the pieces — a piece is a phase, tags of
     different phases are different groups — and the small histogram is all-reduced.  0.5 GB of records per 250 Mbp and
-    rank instead of 0.93 GB of keys, and no rank builds a key set.  Collective: every rank must call it."""
+    rank instead of 0.93 GB of keys, and no rank builds a key set.  Collective: every rank must call it.
+
+    overlap: a callable run while the four large all-to-alls are in flight (they are posted asynchronously; the local
+    steps 1-6 of the rank are independent of them).  Returns the histogram, or (histogram, overlap()) when given."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = ops.device
@@ -373,14 +377,17 @@ def across_records_exchange(ops, eng, seqs, group_of: Sequence[int], k: int, cs:
     smsk = torch.cat([msk[j, :int(send_n[j])] for j in range(world)])
     rrec = torch.empty(int(recv_n.sum()) * 2, dtype=torch.int64, device=cdev)
     rmsk = torch.empty(int(recv_n.sum()), dtype=torch.int32, device=cdev)
-    dist.all_to_all_single(rrec, to_comm(srec), output_split_sizes=[int(n) * 2 for n in recv_n],
-                           input_split_sizes=[int(n) * 2 for n in send_n], group=group)
-    dist.all_to_all_single(rmsk, to_comm(smsk), output_split_sizes=[int(n) for n in recv_n],
-                           input_split_sizes=[int(n) for n in send_n], group=group)
     rcnt = torch.empty((world, spp), dtype=torch.int32, device=cdev)
     roff = torch.empty((world, spp), dtype=torch.int32, device=cdev)
-    dist.all_to_all_single(rcnt.view(-1), to_comm(cnt.view(-1)), group=group)
-    dist.all_to_all_single(roff.view(-1), to_comm(off.view(-1)), group=group)
+    works = [dist.all_to_all_single(rrec, to_comm(srec), output_split_sizes=[int(n) * 2 for n in recv_n],
+                                    input_split_sizes=[int(n) * 2 for n in send_n], group=group, async_op=True),
+             dist.all_to_all_single(rmsk, to_comm(smsk), output_split_sizes=[int(n) for n in recv_n],
+                                    input_split_sizes=[int(n) for n in send_n], group=group, async_op=True),
+             dist.all_to_all_single(rcnt.view(-1), to_comm(cnt.view(-1)), group=group, async_op=True),
+             dist.all_to_all_single(roff.view(-1), to_comm(off.view(-1)), group=group, async_op=True)]
+    local = overlap() if overlap is not None else None      # the rank's own steps 1-6 run under the exchange
+    for w in works:
+        w.wait()
     rrec, rmsk, rcnt, roff = from_comm(rrec), from_comm(rmsk), from_comm(rcnt), from_comm(roff)
     ops.before_wrap()
     trace("all_to_all")
@@ -398,7 +405,7 @@ def across_records_exchange(ops, eng, seqs, group_of: Sequence[int], k: int, cs:
     out = ht.cpu().numpy().astype(np.uint64)
     trace("all_reduce")
     trace.report()
-    return out
+    return out if overlap is None else (out, local)
 
 
 def exp1_step(eng, seqs, group_of: Sequence[int], k: int, cs: int = 5000, hist_len: int = 5001,
@@ -417,8 +424,10 @@ def exp1_step(eng, seqs, group_of: Sequence[int], k: int, cs: int = 5000, hist_l
     lo, hi = eng.SKM_EXCHANGE_K
     if lo <= k <= hi and max(group_of) < 32 and not os.environ.get("KHOICE_DIST_SET_EXCHANGE"):
         # the super-k-mer form on every rank: steps 1-6 locally (no set is built), steps 7-8 by exchange of records
-        res = eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len, across=False)
-        res["across_hist"] = across_records_exchange(ops, eng, seqs, group_of, k, cs, hist_len, group)
+        # (the local run is handed to the exchange: it runs while the packed records travel)
+        across, res = across_records_exchange(ops, eng, seqs, group_of, k, cs, hist_len, group,
+                                              overlap=lambda: eng.exp1_run(seqs, group_of, k, cs=cs, hist_len=hist_len, across=False))
+        res["across_hist"] = across
         res["exchange"] = "records"
         return res
     # the fused local step, emitting only this rank's across-group set (counter = local groups)
