@@ -2509,7 +2509,8 @@ extern "C" int kh_exp1_run(kh_ctx* c, int nseq, const uint8_t* const* seqs, cons
 static bool skm_exchange_k(int k) { return k >= KH_SKM_MIN_K && k <= KH_SKM_MAX_K; }
 
 // slots for `nparts` pieces of at most positions_max k-mer positions each; false: too many k-mers per piece
-static bool skm_exchange_geometry(int k, uint64_t positions_max, int nparts, u32 fan, u64* nslots, double* per_kmer_out) {
+static bool skm_exchange_geometry(int k, uint64_t positions_max, int nparts, u32 fan, u64* nslots, double* per_kmer_out,
+                                  double eff_parts = 0.0 /* pieces that share most k-mers count as fewer; 0: nparts */) {
     const int m15w = k - 15 + 1;
     int m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;
     if (k < 20) m = std::max(11, k - 6);
@@ -2528,7 +2529,8 @@ static bool skm_exchange_geometry(int k, uint64_t positions_max, int nparts, u32
     // kernel's 1024 records.
     const double clump = 0.5 * (double)(w + 1) * (double)std::max<u32>(1, fan);
     auto region = [&](double mean) { return mean * per_kmer * std::max(1.7, 1.0 + 5.0 * std::sqrt(clump / mean)) + 128.0; };
-    double mean = std::min(2600.0 / (0.55 * (double)nparts), (1024.0 - 128.0) / (1.7 * per_kmer));
+    if (eff_parts <= 0.0) eff_parts = (double)nparts;
+    double mean = std::min(2600.0 / (0.55 * eff_parts), (1024.0 - 128.0) / (1.7 * per_kmer));
     while (mean > 64.0 && region(mean) > 1008.0) mean *= 0.95;
     if (const char* e = getenv("KHOICE_SKM_EXCHANGE_MEAN")) mean = std::max(16.0, atof(e));   // tests: rounds on the owner
     u64 ns = std::max<u64>((u64)nparts, (u64)((double)std::max<u64>(1, positions_max) / mean) + 1);
@@ -2646,7 +2648,7 @@ static int skm_pack_impl(kh_ctx* c, int nseq, const uint8_t* const* seqs, const 
 static int skm_phased_impl(kh_ctx* c, int k, int npieces, const void* const* recs, const uint32_t* const* masks,
                            const uint32_t* const* counts, const uint32_t* const* offs, uint32_t nslots, uint32_t cs,
                            uint64_t* hist, uint32_t hist_len, u64* dup_out /* [npieces][32] host or null */, bool* soft_done,
-                           const u32* dup_row = nullptr, const u32* join_next = nullptr);
+                           const u32* dup_row = nullptr, const u32* join_next = nullptr, u32 share_q8 = 256);
 extern "C" int kh_skm_phased_histogram(kh_ctx* c, int k, int npieces, const void* const* recs, const uint32_t* const* masks,
                                        const uint32_t* const* counts, const uint32_t* const* offs, uint32_t nslots, uint32_t cs,
                                        uint64_t* hist, uint32_t hist_len) {
@@ -2654,7 +2656,8 @@ extern "C" int kh_skm_phased_histogram(kh_ctx* c, int k, int npieces, const void
 }
 static int skm_phased_impl(kh_ctx* c, int k, int npieces, const void* const* recs, const uint32_t* const* masks,
                            const uint32_t* const* counts, const uint32_t* const* offs, uint32_t nslots, uint32_t cs,
-                           uint64_t* hist, uint32_t hist_len, u64* dup_out, bool* soft_done, const u32* dup_row, const u32* join_next) {
+                           uint64_t* hist, uint32_t hist_len, u64* dup_out, bool* soft_done, const u32* dup_row, const u32* join_next,
+                           u32 share_q8) {
     if (soft_done) *soft_done = false;
     if (!c || npieces < 1 || !recs || !masks || !counts || !offs || !hist || hist_len < 2 || cs < 1)
         return kh_fail(KH_E_ARG, "kh_skm_phased_histogram: bad argument");
@@ -2683,6 +2686,7 @@ static int skm_phased_impl(kh_ctx* c, int k, int npieces, const void* const* rec
     job.ctl = d_ws.as<u32>();
     job.dup = dup_out ? reinterpret_cast<unsigned long long*>(d_ws.as<u8>() + off_pdup) : nullptr;
     job.npieces = (u32)npieces;
+    job.share_q8 = std::min<u32>(256, std::max<u32>(1, share_q8));
     job.nslots = nslots;
     job.hist_len = hist_len;
     job.cs = cs;
@@ -2730,7 +2734,17 @@ static int exp1_big_group_skm(kh_ctx* c, int n, const uint8_t* const* seqs, cons
     u64 ns = 0;
     double per_kmer = 0;
     const bool dbg = getenv("KHOICE_SKM_DEBUG") != nullptr;
-    if (!skm_exchange_geometry(k, pos_max, P, (u32)SUB, &ns, &per_kmer)) {
+    // How much the sub-batches of a group share decides how large a slot may be: its table holds one sub-batch's k-mers
+    // plus what each further one adds (`novelty` of its own).  Measured: the synthetic genomes (1 % divergence from one
+    // ancestor, independent per genome) add 0.7 — with 0.3 assumed a table overfilled and the repeated launch cost more
+    // than the 2.5 x larger slots saved (12.1 -> 14.0 ms) — so the default assumes unrelated sub-batches (1.0); real
+    // collections with a tree-like history share more: KHOICE_SKM_PHASED_NOVELTY (an overfilled table is caught and the
+    // launch repeated with rounds sized for unrelated pieces).
+    double novelty = 1.0;
+    if (const char* e = getenv("KHOICE_SKM_PHASED_NOVELTY")) novelty = std::min(1.0, std::max(0.05, atof(e)));
+    const double eff_parts = 1.0 + novelty * (double)(P - 1);
+    const u32 share_q8 = (u32)std::min(256.0, std::ceil(256.0 * eff_parts / (double)P));
+    if (!skm_exchange_geometry(k, pos_max, P, (u32)SUB, &ns, &per_kmer, eff_parts)) {
         if (dbg) fprintf(stderr, "[skm phased] %d genomes in %d phases: no geometry for %llu positions per phase\n", n, P, (unsigned long long)pos_max);
         return KH_OK;
     }
@@ -2835,7 +2849,13 @@ static int exp1_big_group_skm(kh_ctx* c, int n, const uint8_t* const* seqs, cons
     std::vector<u64> pdup((size_t)recs.size() * 32, 0), hist(hist_len, 0);
     bool ok = false;
     KHCHK(skm_phased_impl(c, k, (int)recs.size(), recs.data(), masks.data(), counts.data(), offs.data(), nslots, cs, hist.data(), hist_len,
-                          pdup.data(), &ok, rows.data(), joins.data()));
+                          pdup.data(), &ok, rows.data(), joins.data(), share_q8));
+    if (!ok && share_q8 < 256) {   // a table overfilled: the genomes share less than assumed — rounds for unrelated pieces
+        if (dbg) fprintf(stderr, "[skm phased] a table overfilled with rounds sized for shared k-mers: once more\n");
+        c->stat.retries++;
+        KHCHK(skm_phased_impl(c, k, (int)recs.size(), recs.data(), masks.data(), counts.data(), offs.data(), nslots, cs, hist.data(),
+                              hist_len, pdup.data(), &ok, rows.data(), joins.data(), 256));
+    }
     if (!ok) {
         if (dbg) fprintf(stderr, "[skm phased] the phased union overflowed\n");
         return KH_OK;

@@ -201,6 +201,8 @@ struct KhSkmPhasedJob {
     u32* ctl;                       // [0] error bits
     unsigned long long* dup;        // [npieces][32] or null: per (piece, tag), instances that repeat a k-mer of the same tag
     u32 npieces, nslots, hist_len, cs;
+    u32 share_q8;                   // distinct k-mers expected per 256 instances of a slot (256: the pieces share nothing;
+                                    // sub-batches of one group share most): the rounds of a slot are sized from it
     int k;
 };
 constexpr u32 KH_SKM_PHASED_MAX_DUP_PIECES = 32;   // pieces whose repeats can be counted (LDS counters)

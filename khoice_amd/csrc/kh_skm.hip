@@ -1136,7 +1136,10 @@ __global__ __launch_bounds__(NT) void k_skm_pack(const KhSkmPackJob jb) {
     }
 }
 
-constexpr u32 SKM_PH_NT = 1024, SKM_PH_T = 4096, SKM_PH_T2 = 128, SKM_PH_MAXCH = 3072, SKM_PH_HBINS = 512;
+constexpr u32 SKM_PH_NT = 1024, SKM_PH_T = 4096, SKM_PH_T2 = 128, SKM_PH_MAXCH = 4096, SKM_PH_HBINS = 512;
+// A phase holds a few dozen records and its time is the insertion's chain of LDS round trips (ablation: 64 % of the
+// kernel): ONE k-mer per thread — twice the threads of the union's two-k-mer chunks, half the chain.
+constexpr u32 SKM_PH_E = 1, SKM_PH_OB = 5;   // k-mers per chunk; a record has at most 1 << SKM_PH_OB chunks
 constexpr u32 SKM_PH_ROUND = 3072;   // k-mer instances a round of the phased union takes (the table has 4096 entries)
 constexpr u32 SKM_PH_STAGED = 32;    // pieces whose records of a slot are numbered in one go (more: a phase at a time)
 size_t kh_skm_phased_lds_bytes() {
@@ -1152,7 +1155,7 @@ size_t kh_skm_phased_lds_bytes() {
 __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJob jb) {
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     constexpr u32 NT = SKM_PH_NT, T = SKM_PH_T, T2 = SKM_PH_T2, HBITS = 12, NP = SKM_PH_STAGED;
-    constexpr int E = (int)SKM_UE;
+    constexpr int E = (int)SKM_PH_E;
     constexpr u64 EMPTY = ~0ull;
     u8* p = lds_raw;
     unsigned long long* tkey = reinterpret_cast<unsigned long long*>(p);   p += (size_t)T * 8;
@@ -1264,6 +1267,10 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
     };
     auto fold_now = [&]() {
         __syncthreads();
+#if defined(KH_PH_ABLATE) && KH_PH_ABLATE == 2   // (timing study 2: barriers without the fold's work)
+        __syncthreads();
+        return;
+#endif
         uint4 m4 = reinterpret_cast<uint4*>(tmlo)[tid];
         if (m4.x | m4.y | m4.z | m4.w) {
             uint4 c4 = reinterpret_cast<uint4*>(tcnt)[tid];
@@ -1334,8 +1341,8 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
                     all_staged = false;
                 } else if (myph < NP) {
 #pragma unroll
-                    for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
-                        if (cc < my_nch) owner[my_cstart + cc] = (u16)((tid << SKM_OB) | cc);
+                    for (u32 cc = 0; cc < (1u << SKM_PH_OB); ++cc)
+                        if (cc < my_nch) owner[my_cstart + cc] = (u16)((tid << SKM_PH_OB) | cc);
                     if (myidx == 0) cbeg[myph] = my_cstart;
                     if (myidx + 1 == mycnt) cend[myph] = my_cstart + my_nch;
                 }
@@ -1357,7 +1364,7 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
             }
             __syncthreads();
         }
-        const u32 R = (scratch[2] + SKM_PH_ROUND - 1u) / SKM_PH_ROUND;
+        const u32 R = (((scratch[2] * jb.share_q8) >> 8) + SKM_PH_ROUND - 1u) / SKM_PH_ROUND;   // (an optimistic share_q8 that overfills a table is caught at the fold: the host runs the launch again with 256)
         for (u32 q = 0; q < R; ++q) {
             {   // a fresh table (the read-out before it is behind a barrier)
                 uint4* k4 = reinterpret_cast<uint4*>(tkey);
@@ -1372,24 +1379,30 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
             // A phase = a piece and the pieces joined to it (join_next: the same tags — a sub-batch's side list): the fold
             // comes behind the last of them that holds records of this slot.
             bool open = false;   // uniform: insertions since the last fold
+#if defined(KH_PH_ABLATE) && KH_PH_ABLATE == 3   // (timing study 3: no phases at all)
+            if (false) {
+#else
             if (all_staged) {
+#endif
                 for (u32 ph = 0; ph < npieces; ++ph) {
                     const u32 c0 = cbeg[ph], c1 = cend[ph], fl = pflag[ph];
                     if (c0 != c1) {   // uniform
                         const uint4* __restrict__ rec = prec[ph] + poff[ph];
                         const u32* __restrict__ msk = pmsk[ph] + poff[ph];
                         u32 fresh_n = 0;
+#if !defined(KH_PH_ABLATE) || KH_PH_ABLATE != 1   // (timing study 1: no insertion)
                         for (u32 c = c0 + tid; c < c1; c += NT) {
-                            const u32 o = owner[c], ri = rloc[o >> SKM_OB] & 1023u;
-                            insert_chunk(rec[ri], msk[ri], (o & ((1u << SKM_OB) - 1u)) * (u32)E, fl >> 1, R, q, fresh_n);
+                            const u32 o = owner[c], ri = rloc[o >> SKM_PH_OB] & 1023u;
+                            insert_chunk(rec[ri], msk[ri], (o & ((1u << SKM_PH_OB) - 1u)) * (u32)E, fl >> 1, R, q, fresh_n);
                         }
+#endif
                         count_fresh(fresh_n);
                         open = true;
                     }
                     if (open && !((fl & 1u) && ph + 1 < npieces)) { fold_now(); open = false; }
                 }
             } else {
-                constexpr u32 BATCH = SKM_PH_MAXCH >> SKM_OB;   // records numbered at a time: their chunks fit the owner table
+                constexpr u32 BATCH = SKM_PH_MAXCH >> SKM_PH_OB;   // records numbered at a time: their chunks fit the owner table
                 u32 par = 0;
                 for (u32 ph = 0; ph < npieces; ++ph) {
                     const KhSkmPiece pc = jb.pieces[ph];
@@ -1412,17 +1425,17 @@ __global__ __launch_bounds__(SKM_PH_NT, 8) void k_skm_phased(const KhSkmPhasedJo
                             wbase = (u32)__builtin_amdgcn_readlane((int)wbase, KH_WAVE - 1);
                             const u32 cstart = wbase + incl - nch;
 #pragma unroll
-                            for (u32 cc = 0; cc < (1u << SKM_OB); ++cc)
-                                if (cc < nch) owner[cstart + cc] = (u16)((tid << SKM_OB) | cc);
+                            for (u32 cc = 0; cc < (1u << SKM_PH_OB); ++cc)
+                                if (cc < nch) owner[cstart + cc] = (u16)((tid << SKM_PH_OB) | cc);
                         }
                         __syncthreads();
-                        const u32 C = scratch[par];   // (<= BATCH << SKM_OB = SKM_PH_MAXCH)
+                        const u32 C = scratch[par];   // (<= BATCH << SKM_PH_OB = SKM_PH_MAXCH)
                         par ^= 3u;                    // the batches' chunk counters alternate: [0] and [3]
                         if (tid == 0) scratch[par] = 0;   // (the next batch's: nobody reads it before the barrier below)
                         u32 fresh_n = 0;   // entries this thread created
                         for (u32 c = tid; c < C; c += NT) {
-                            const u32 o = owner[c], ri = b0 + (o >> SKM_OB);
-                            insert_chunk(rec[ri], msk[ri], (o & ((1u << SKM_OB) - 1u)) * (u32)E, pc.dup_row, R, q, fresh_n);
+                            const u32 o = owner[c], ri = b0 + (o >> SKM_PH_OB);
+                            insert_chunk(rec[ri], msk[ri], (o & ((1u << SKM_PH_OB) - 1u)) * (u32)E, pc.dup_row, R, q, fresh_n);
                         }
                         count_fresh(fresh_n);
                         open = true;
