@@ -1528,6 +1528,17 @@ static int group_union_incremental(kh_ctx* c, const std::vector<int>& members, c
 // slot.  Takes what the key-array form below takes when k is in [KH_SKM_MIN_K, KH_SKM_MAX_K], nothing is
 // emitted and the batch fits one slot grid; *done == false: not applicable, or a region overflowed
 // (low-complexity input, far more records than estimated) — the caller goes on to the key-array form.
+// Minimizer length of the one-word super-k-mer form.  A longer window (shorter minimizer) makes longer runs: fewer,
+// longer records for all three kernels — as long as the 4^m minimizers still spread over the slots (m = 11 overfills
+// too many).  Measured on the headline shape (ms per step, m = 15 / 13 / 12): k = 21 3.40 / 2.95 / 2.87, k = 24
+// 2.84 / 2.60 / 2.57, k = 27 2.53 / 2.47 / 2.51; from k = 28 the record's 24 .. 27 k-mers are the limit, not the window
+// (k = 30 .. 32: no difference): m = 16 where that makes the window a power of two, else 15.
+static int skm_minimizer_len(int k) {
+    if (k <= 24) return std::max(11, std::min(12, k - 6));   // k = 18 .. 24: 12 (the kernels alone, k = 15 .. 17: k - 6, at least 11)
+    if (k <= 27) return 13;
+    const int m15w = k - 15 + 1;                                   // m-mers per k-mer with m = 15
+    return (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;
+}
 // by_group: the operands of the union are the GROUPS (every record carries its genome's group number): only the
 // across-group histogram comes out — the second pass of a run over more than 64 genomes, whose batches of
 // whole groups have answered the within-group questions.
@@ -1584,9 +1595,7 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
     int m;
     u32 w, nmax;
     if (!two) {
-        const int m15w = k - 15 + 1;                                   // m-mers per k-mer with m = 15
-        m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;   // m = 16 when that makes w a power of two
-        if (k < 20) m = std::max(11, k - 6);                           // short k-mers: windows of 7 (5 at k = 15) shorter m-mers (hot minimizers: k_skm_big)
+        m = skm_minimizer_len(k);
         if (const char* e = getenv("KHOICE_SKM_M")) m = std::min(16, std::max(2, atoi(e)));   // experiments
         if (m >= k) return KH_OK;
         w = (u32)(k - m + 1);
@@ -2511,9 +2520,7 @@ static bool skm_exchange_k(int k) { return k >= KH_SKM_MIN_K && k <= KH_SKM_MAX_
 // slots for `nparts` pieces of at most positions_max k-mer positions each; false: too many k-mers per piece
 static bool skm_exchange_geometry(int k, uint64_t positions_max, int nparts, u32 fan, u64* nslots, double* per_kmer_out,
                                   double eff_parts = 0.0 /* pieces that share most k-mers count as fewer; 0: nparts */) {
-    const int m15w = k - 15 + 1;
-    int m = (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;
-    if (k < 20) m = std::max(11, k - 6);
+    const int m = skm_minimizer_len(k);
     const u32 w = (u32)(k - m + 1);
     // k-mer instances per slot and rank: the pack kernel takes 1024 records of a slot; the owner's table (4096 entries)
     // has to hold the slot's distinct k-mers of ALL ranks — sized for unrelated groups: nparts x the per-rank mean
