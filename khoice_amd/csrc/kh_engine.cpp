@@ -1603,8 +1603,10 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         if (!kh_skm_supports_w(w)) return KH_OK;
     } else {   // the scatter exists for every third window width: one of m = 16, 15, 14 fits
         m = 16;
-        while (m >= 14 && !kh_skm2_supports_w((u32)(k - m + 1))) --m;
-        if (m < 14) return KH_OK;
+        if (const char* e = getenv("KHOICE_SKM2_M")) m = std::min(16, std::max(10, atoi(e)));   // experiments: the first length tried
+        const int m_lo = m - 2;
+        while (m >= m_lo && !kh_skm2_supports_w((u32)(k - m + 1))) --m;
+        if (m < m_lo) return KH_OK;
         w = (u32)(k - m + 1);
         nmax = (u32)std::min(63, 118 - k);
     }
