@@ -1534,7 +1534,8 @@ static int group_union_incremental(kh_ctx* c, const std::vector<int>& members, c
 // 2.84 / 2.60 / 2.57, k = 27 2.53 / 2.47 / 2.51; from k = 28 the record's 24 .. 27 k-mers are the limit, not the window
 // (k = 30 .. 32: no difference): m = 16 where that makes the window a power of two, else 15.
 static int skm_minimizer_len(int k) {
-    if (k <= 24) return std::max(11, std::min(12, k - 6));   // k = 18 .. 24: 12 (the kernels alone, k = 15 .. 17: k - 6, at least 11)
+    if (k <= 24) return k >= 17 ? 12 : 11;   // k = 17 .. 24: 12 (k = 17: windows of 6, 3.75 ms against 4.6 with 11 bases and 4.4 with key
+                                             // arrays); the kernels alone at k = 15, 16: 11
     if (k <= 27) return 13;
     const int m15w = k - 15 + 1;                                   // m-mers per k-mer with m = 15
     return (m15w > 1 && ((m15w - 1) & (m15w - 2)) == 0) ? 16 : 15;
@@ -1564,9 +1565,9 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
                     SkmRecords* rec_out = nullptr) {
     *done = false;
     {
-        // k = 18, 19 on the headline shape: 3.6 / 3.5 ms against 4.5 with key arrays; k = 17 with minimizers of 11 bases
-        // overfills too many slots, with 12 (windows of 6) the scatter alone takes 2 ms: below 18 the key arrays stay
-        // (KHOICE_SKM_MIN_K: experiments and tests, the kernels take k >= 15)
+        // k = 17 .. 19 on the headline shape: 3.75 / 3.6 / 3.3 ms against 4.4 with key arrays; k = 16 and 15 (windows of 5
+        // or 6 over 11 bases: too many overfull slots; over 12: twice the coarse buckets) 5.2 / 6.7 ms: below 17 the key
+        // arrays stay (KHOICE_SKM_MIN_K: experiments and tests, the kernels take k >= 15)
         int min_k = KH_SKM_MIN_K;
         if (const char* e = getenv("KHOICE_SKM_MIN_K")) min_k = std::max(15, atoi(e));
         if (k < min_k || k > KH_SKM2_MAX_K || getenv("KHOICE_NO_SKM")) return KH_OK;

@@ -128,7 +128,7 @@ constexpr u32 KH_SKM_STAGE = KH_TUNE_SKM_STAGE;   // records counting-sorted in 
 constexpr u32 KH_SKM_MAX_COARSE = 256;    // coarse buckets (LDS counters of the scatter); 512 (KH_SKM2_MAX_COARSE) for inputs too large for 256
 constexpr u32 KH_SKM_MAX_FINE = 512;      // slots per coarse bucket (9 bits in the record)
 constexpr u32 KH_SKM_MAX_CAP2 = 1024;     // records of one slot with one-word keys: one per thread of the union (512 with the 2048-entry table)
-constexpr int KH_SKM_MIN_K = 18, KH_SKM_MAX_K = 32;   // (k = 18, 19: minimizers of k - 6 bases; the kernels take k >= 15)
+constexpr int KH_SKM_MIN_K = 17, KH_SKM_MAX_K = 32;   // (below 17 the key arrays are faster; the kernels take k >= 15)
 #ifndef KH_TUNE_SKM_CUR1_STRIDE
 #define KH_TUNE_SKM_CUR1_STRIDE 1088
 #endif

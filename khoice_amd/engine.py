@@ -549,7 +549,7 @@ class Engine:
         return res
 
     # -- steps 7-8 across ranks by exchange of minimizer records (khoice_amd/dist.py; 20 <= k <= 32)
-    SKM_EXCHANGE_K = (18, 32)
+    SKM_EXCHANGE_K = (17, 32)
 
     def skm_exchange_plan(self, k: int, positions_max: int, fan_max: int, nparts: int):
         """(nslots, slots_per_part, part_cap): the slot geometry every rank must use, from numbers the ranks agreed on."""

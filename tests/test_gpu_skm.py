@@ -55,7 +55,7 @@ def check(eng, seqs, group_of, k, cs=5000, hist_len=5001, expect_skm=True):
 
 @pytest.mark.parametrize("k", [15, 16, 17])
 def test_skm_kernels_take_short_kmers(eng, k, monkeypatch):
-    """kh_exp1_run leaves k < 18 to the key arrays (the minimizers would be too short to spread); the kernels themselves
+    """kh_exp1_run leaves k < 17 to the key arrays (the minimizers would be too short to spread); the kernels themselves
     take k >= 15 — keys that fit the low word up to k = 16: the rolled strands are masked in both halves."""
     monkeypatch.setenv("KHOICE_SKM_MIN_K", "15")
     items = synth.species_set(3, 3, 60_000)
@@ -64,10 +64,10 @@ def test_skm_kernels_take_short_kmers(eng, k, monkeypatch):
     check(eng, seqs, group_of, k)
 
 
-@pytest.mark.parametrize("k", [18, 19, 20, 21, 23, 24, 27, 30, 31, 32])
+@pytest.mark.parametrize("k", [17, 18, 19, 20, 21, 23, 24, 27, 30, 31, 32])
 def test_skm_matches_oracle_over_k(eng, k):
-    """Every minimizer geometry: w a power of two (k = 23, 30, 31) and not (two overlapping windows); k = 18, 19:
-    minimizers of 12 and 13 bases."""
+    """Every minimizer geometry: minimizers of 12 bases (k = 17 .. 24: windows of 6 .. 13), 13 (k = 27), 15 and 16; w a
+    power of two (k = 27, 30, 31) and not (two overlapping windows)."""
     items = synth.species_set(3, 3, 60_000)
     seqs = [t for _, _, t in items]
     group_of = [s - 1 for s, _, _ in items]
@@ -305,5 +305,5 @@ def test_skm_random_shapes(eng):
                     t[rng.randrange(len(t))] = rng.choice("ACGTN")
                 seqs.append("".join(t).encode())
                 group_of.append(g)
-        k = rng.randint(18, 32)
+        k = rng.randint(17, 32)
         check(eng, seqs, group_of, k, cs=rng.choice([1, 2, 5000]), hist_len=rng.choice([2, 8, 5001]), expect_skm=False)
