@@ -1659,7 +1659,9 @@ static int exp1_skm(kh_ctx* c, int nseq, const uint8_t* const* seqs, const uint6
         const u64 lim = (u64)KH_SKM_MAX_COARSE * KH_SKM_MAX_FINE;
         const double per_slot = (double)total_pos * per_kmer / (double)lim;
         const double s2 = ((double)max_cap2 - 112.0) / per_slot;
-        if (s2 >= 1.4) { nslots64 = lim; slack2 = std::min(slack2, s2); }
+        double s2_min = 1.4;
+        if (const char* e = getenv("KHOICE_SKM_MIN_SLACK")) s2_min = std::max(1.0, atof(e));   // experiments
+        if (s2 >= s2_min) { nslots64 = lim; slack2 = std::min(slack2, s2); }
     }
     // two-word keys a little above 512 x 1024 slots (configs[2] at k = 41, the pass by group over 500 M positions):
     // the same cut, up to what the union's table takes in one go on average
