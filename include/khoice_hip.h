@@ -246,9 +246,10 @@ void kh_mix_host(int k, const uint64_t *key_words, uint64_t *out_words);
 void kh_unmix_host(int k, const uint64_t *key_words, uint64_t *out_words);
 
 /* ---------------------------------------------------------------- steps 7-8 across ranks, exchange of records
- * (workflow/rules/exp_type_1.smk:243-259 when the groups live on several GPUs; 20 <= k <= 32).
+ * (workflow/rules/exp_type_1.smk:243-259 when the groups live on several GPUs; 17 <= k <= 32).
  * kh_skm_exchange_plan: the slot geometry all ranks must share, from numbers they agreed on (the largest rank's number
- *   of k-mer positions, the largest group of any rank).
+ *   of k-mer positions, the largest group of any rank: its genomes bring their copies of a locus into a slot together,
+ *   which sizes the slot's region).
  * kh_skm_pack: this rank's genomes -> minimizer records tagged with the LOCAL group number tag_of[i] (0..31), identical
  *   records merged, packed by owner of their slot into CALLER-ALLOCATED device buffers: rec_out [nparts][part_cap] x 16
  *   bytes, mask_out [nparts][part_cap], count_out / off_out [nparts][slots_per_part] (records of a slot and where they
