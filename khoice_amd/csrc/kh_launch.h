@@ -187,6 +187,18 @@ struct KhSkmPackJob {
     u32 nsub;                       // cursors per part (slot s uses cursor s % nsub over 1 / nsub of the part's array): 1 = the
                                     // part is filled without gaps (it travels); more = no single hot atomic (one GPU)
 };
+struct KhSkmCompactJob {            // a part packed through several cursors -> the same records without gaps (they travel)
+    const uint4* tmp_rec;           // [nparts][part_cap], sub-range q of a part at q * (part_cap / nsub)
+    const u32* tmp_mask;
+    uint4* out_rec;                 // [nparts][part_cap], filled from 0
+    u32* out_mask;
+    const u32* cursors;             // [nparts][nsub] records per sub-range
+    u32* slot_off;                  // [nslots] rewritten to the compacted positions
+    u32* part_n;                    // [nparts] out: records of the part
+    u64 part_cap;
+    u32 nslots, spp, nsub, nparts;
+};
+void kh_launch_skm_pack_compact(const KhSkmCompactJob& job, hipStream_t st);
 struct KhSkmPiece {                 // what one source rank sent for this rank's slots
     const uint4* rec;
     const u32* mask;

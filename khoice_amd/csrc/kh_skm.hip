@@ -1136,6 +1136,32 @@ __global__ __launch_bounds__(NT) void k_skm_pack(const KhSkmPackJob jb) {
     }
 }
 
+// A part that was packed through 64 cursors (one returning atomic per slot on a single cursor is a queue: 78 K
+// workgroups, 0.8 ms) is moved together: workgroup (sub-range, part) copies its records behind those of the sub-ranges
+// before it and rewrites the offsets of its slots.
+__global__ __launch_bounds__(256) void k_skm_pack_compact(const KhSkmCompactJob jb) {
+    const u32 sub = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    u32 before = 0, total = 0;
+    for (u32 q = 0; q < jb.nsub; ++q) {   // uniform
+        const u32 v = jb.cursors[part * jb.nsub + q];
+        before += q < sub ? v : 0u;
+        total += v;
+    }
+    const u32 n = jb.cursors[part * jb.nsub + sub];
+    const u64 subcap = jb.part_cap / jb.nsub;
+    const u64 src = (u64)part * jb.part_cap + (u64)sub * subcap, dst = (u64)part * jb.part_cap + before;
+    for (u32 i = tid + 256u * blockIdx.z; i < n; i += 256u * gridDim.z) {   // (z: slices of the copy)
+        jb.out_rec[dst + i] = jb.tmp_rec[src + i];
+        jb.out_mask[dst + i] = jb.tmp_mask[src + i];
+    }
+    if (blockIdx.z) return;
+    const u32 s0 = part * jb.spp, s1 = s0 + jb.spp < jb.nslots ? s0 + jb.spp : jb.nslots;
+    const u32 first = s0 + (sub + jb.nsub - s0 % jb.nsub) % jb.nsub;   // the part's first slot with slot % nsub == sub
+    for (u32 slot = first + tid * jb.nsub; slot < s1; slot += 256u * jb.nsub)
+        jb.slot_off[slot] = jb.slot_off[slot] - (u32)((u64)sub * subcap) + before;
+    if (sub == 0 && tid == 0) jb.part_n[part] = total;
+}
+
 constexpr u32 SKM_PH_NT = 1024, SKM_PH_T = 4096, SKM_PH_T2 = 128, SKM_PH_MAXCH = 4096, SKM_PH_HBINS = 512;
 // A phase holds a few dozen records and its time is the insertion's chain of LDS round trips (ablation: 64 % of the
 // kernel): ONE k-mer per thread — twice the threads of the union's two-k-mer chunks, half the chain.
@@ -1524,6 +1550,11 @@ void kh_launch_skm_pack(const KhSkmPackJob& job, hipStream_t st) {
         skm_allow_lds(k_skm_pack<1024>, lds);
         hipLaunchKernelGGL(k_skm_pack<1024>, dim3(job.nslots), dim3(1024), lds, st, job);
     }
+}
+void kh_launch_skm_pack_compact(const KhSkmCompactJob& job, hipStream_t st) {
+    if (!job.nparts || !job.nsub) return;
+    const u32 z = job.nparts >= 16 ? 1u : 16u / job.nparts;   // about a thousand workgroups
+    hipLaunchKernelGGL(k_skm_pack_compact, dim3(job.nsub, job.nparts, z), dim3(256), 0, st, job);
 }
 void kh_launch_skm_phased(const KhSkmPhasedJob& job, u32 grid, hipStream_t st) {
     if (!job.nslots || !grid) return;
