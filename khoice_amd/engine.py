@@ -548,7 +548,7 @@ class Engine:
             res["across_set"] = KmerSet(self, aset.value)
         return res
 
-    # -- steps 7-8 across ranks by exchange of minimizer records (khoice_amd/dist.py; 20 <= k <= 32)
+    # -- steps 7-8 across ranks by exchange of minimizer records (khoice_amd/dist.py; 17 <= k <= 32)
     SKM_EXCHANGE_K = (17, 32)
 
     def skm_exchange_plan(self, k: int, positions_max: int, fan_max: int, nparts: int):
